@@ -1,0 +1,200 @@
+"""ctypes front-ends of the CPU checkers + partition comparison helpers.  TEST INFRASTRUCTURE.
+
+``run_csegment``    our restatement of the reference C++ merger (oracle/csegment_oracle.cpp)
+``run_reference``   the reference's own segment.cc, compiled unmodified into oracle/_ref/
+                    (present only if oracle/Makefile ran where /root/reference exists)
+``run_pysegmenter`` our restatement of the reference Python merger (oracle/pysegmenter_oracle.cpp)
+
+The host-side preprocessing mirrors the reference binding ``utils/csegment/c_segment.pyx:53-84``
+(clip to [eps32, 1-eps32], int32 offset array, -1-terminated class table read over
+``range(H*W-1)``) and, for the Python variant, ``utils/segmenter.py:232-234``.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import os
+import subprocess
+import sys
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+EPS32 = np.finfo(np.float32).eps
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+
+def build(verbose: bool = False) -> None:
+    """Compile the checkers (and oracle/_ref when the reference tree is present)."""
+    res = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building the oracle failed")
+
+
+def _load(name: str) -> ctypes.CDLL:
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    return ctypes.CDLL(path)
+
+
+def have_reference() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libcsegment_ref.so"))
+
+
+@contextlib.contextmanager
+def _quiet_stdout():
+    """The reference prints progress to C++ cout; keep test logs readable."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(devnull, 1)
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+
+
+@dataclass
+class OracleResult:
+    mask: np.ndarray                 # int32 [H, W]; 0 = every class-0 object, 1..K instances
+    object_class: List[int]          # class of label k at index k-1
+    partition: Optional[np.ndarray]  # int32 [H, W] surviving object id, before the class-0 collapse
+    total_logprob: Optional[float]
+    stats: dict
+
+
+def _prep(class_probs, same_probs, offsets, dtype=np.float32):
+    cp = np.ascontiguousarray(np.asarray(class_probs).clip(EPS32, 1.0 - EPS32), dtype=dtype)
+    sp = np.ascontiguousarray(np.asarray(same_probs).clip(EPS32, 1.0 - EPS32), dtype=dtype)
+    if cp.ndim != 3 or sp.ndim != 3 or cp.shape[1:] != sp.shape[1:]:
+        raise ValueError("class_probs [C,H,W] and same_probs [O,H,W] must share H, W")
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32).reshape(-1, 2))
+    if off.shape[0] != sp.shape[0]:
+        raise ValueError("len(offsets) must equal same_probs.shape[0]")
+    return cp, sp, off
+
+
+def _class_list(table: np.ndarray) -> List[int]:
+    out = []
+    for i in range(table.shape[0] - 1):       # c_segment.pyx:80-84 reads range(H*W - 1)
+        if table[i] == -1:
+            break
+        out.append(int(table[i]))
+    return out
+
+
+def run_csegment(class_probs, same_probs, num_classes: int, offsets: Sequence[Tuple[int, int]],
+                 same_different_bias: float = 0.0, object_merge_factor: float = 1.0,
+                 merge_logprob_bias: float = 0.0) -> OracleResult:
+    lib = _load("libcsegment_oracle.so")
+    fn = lib.oracle_csegment_run
+    fn.restype = ctypes.c_int
+    fn.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_int, _i32p, _i32p, _i32p, ctypes.c_float, ctypes.c_float,
+                   ctypes.c_float, _i32p, _f64p]
+    cp, sp, off = _prep(class_probs, same_probs, offsets)
+    C, H, W = cp.shape
+    mask = np.zeros((H, W), np.int32)
+    table = np.zeros(H * W, np.int32)
+    part = np.zeros((H, W), np.int32)
+    stats = np.zeros(8, np.float64)
+    rc = fn(cp.ctypes.data_as(_f32p), C, sp.ctypes.data_as(_f32p), sp.shape[0], W, H,
+            int(num_classes), off.ctypes.data_as(_i32p), mask.ctypes.data_as(_i32p),
+            table.ctypes.data_as(_i32p), float(same_different_bias), float(object_merge_factor),
+            float(merge_logprob_bias), part.ctypes.data_as(_i32p), stats.ctypes.data_as(_f64p))
+    if rc != 0:
+        raise ValueError("oracle_csegment_run rejected its arguments (code %d)" % rc)
+    names = ["total_logprob", "n_objects", "n_pops", "n_merges", "t_build_s", "t_loop_s",
+             "n_rescored", "n_initial_records"]
+    return OracleResult(mask, _class_list(table), part, float(stats[0]),
+                        dict(zip(names, stats.tolist())))
+
+
+def run_reference(class_probs, same_probs, num_classes: int, offsets: Sequence[Tuple[int, int]],
+                  same_different_bias: float = 0.0, object_merge_factor: float = 1.0,
+                  merge_logprob_bias: float = 0.0) -> OracleResult:
+    """The reference's own compiled segment.cc (ABI: utils/csegment/segment.cc:742-754)."""
+    lib = ctypes.CDLL(os.path.join(_HERE, "_ref", "libcsegment_ref.so"))
+    fn = lib.c_run_segmentation
+    fn.restype = None
+    fn.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_int, _i32p, _i32p, _i32p, ctypes.c_float, ctypes.c_float,
+                   ctypes.c_float]
+    cp, sp, off = _prep(class_probs, same_probs, offsets)
+    C, H, W = cp.shape
+    mask = np.zeros((H, W), np.int32)
+    table = np.zeros(H * W, np.int32)
+    with _quiet_stdout():
+        fn(cp.ctypes.data_as(_f32p), C, sp.ctypes.data_as(_f32p), sp.shape[0], W, H,
+           int(num_classes), off.ctypes.data_as(_i32p), mask.ctypes.data_as(_i32p),
+           table.ctypes.data_as(_i32p), float(same_different_bias), float(object_merge_factor),
+           float(merge_logprob_bias))
+    return OracleResult(mask, _class_list(table), None, None, {})
+
+
+# ---------------------------------------------------------------------------------------------
+# comparison helpers
+
+
+def canonical(labels: np.ndarray) -> np.ndarray:
+    """Relabel by first occurrence in row-major order (0, 1, 2, ...)."""
+    flat = np.asarray(labels).reshape(-1)
+    _, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first))
+    return order[inv].reshape(np.asarray(labels).shape).astype(np.int64)
+
+
+def same_partition(a: np.ndarray, b: np.ndarray) -> bool:
+    return bool(np.array_equal(canonical(a), canonical(b)))
+
+
+def partition_mismatch(a: np.ndarray, b: np.ndarray) -> int:
+    """Number of pixels whose part in ``a`` is not matched 1:1 to a part of ``b``."""
+    ca, cb = canonical(a).reshape(-1), canonical(b).reshape(-1)
+    pairs, counts = np.unique(np.stack([ca, cb], 1), axis=0, return_counts=True)
+    best_a = {}
+    for (x, y), n in zip(pairs, counts):
+        if n > best_a.get(x, (None, 0))[1]:
+            best_a[x] = (y, n)
+    used = {}
+    good = 0
+    for x, (y, n) in best_a.items():
+        if y in used:
+            continue
+        size_a = int((ca == x).sum())
+        size_b = int((cb == y).sum())
+        if size_a == n and size_b == n:
+            good += n
+            used[y] = x
+    return int(ca.size - good)
+
+
+def masks_equivalent(mask_a, classes_a, mask_b, classes_b) -> bool:
+    """Instance masks equal up to a permutation of labels 1..K, with equal per-label class."""
+    ma, mb = np.asarray(mask_a), np.asarray(mask_b)
+    if ma.shape != mb.shape or len(classes_a) != len(classes_b):
+        return False
+    if not np.array_equal(ma == 0, mb == 0):
+        return False
+    if not same_partition(ma, mb):
+        return False
+    flat_a, flat_b = ma.reshape(-1), mb.reshape(-1)
+    _, idx = np.unique(flat_a, return_index=True)
+    for i in idx:
+        la, lb = int(flat_a[i]), int(flat_b[i])
+        if la == 0:
+            continue
+        if classes_a[la - 1] != classes_b[lb - 1]:
+            return False
+    return True
