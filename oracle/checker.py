@@ -108,7 +108,7 @@ def run_csegment(class_probs, same_probs, num_classes: int, offsets: Sequence[Tu
     mask = np.zeros((H, W), np.int32)
     table = np.zeros(H * W, np.int32)
     part = np.zeros((H, W), np.int32)
-    stats = np.zeros(8, np.float64)
+    stats = np.zeros(10, np.float64)
     rc = fn(cp.ctypes.data_as(_f32p), C, sp.ctypes.data_as(_f32p), sp.shape[0], W, H,
             int(num_classes), off.ctypes.data_as(_i32p), mask.ctypes.data_as(_i32p),
             table.ctypes.data_as(_i32p), float(same_different_bias), float(object_merge_factor),
@@ -116,7 +116,7 @@ def run_csegment(class_probs, same_probs, num_classes: int, offsets: Sequence[Tu
     if rc != 0:
         raise ValueError("oracle_csegment_run rejected its arguments (code %d)" % rc)
     names = ["total_logprob", "n_objects", "n_pops", "n_merges", "t_build_s", "t_loop_s",
-             "n_rescored", "n_initial_records"]
+             "n_rescored", "n_initial_records", "n_live_pops", "_"]
     return OracleResult(mask, _class_list(table), part, float(stats[0]),
                         dict(zip(names, stats.tolist())))
 
@@ -198,3 +198,47 @@ def masks_equivalent(mask_a, classes_a, mask_b, classes_b) -> bool:
         if classes_a[la - 1] != classes_b[lb - 1]:
             return False
     return True
+
+
+# ---------------------------------------------------------------------------------------------
+# Python-variant restatement (utils/segmenter.py semantics, float64)
+
+
+class PySegmenterError(Exception):
+    """Raised where the reference Python raises (NameError / KeyError / AssertionError)."""
+
+
+def run_pysegmenter(class_probs, same_probs, num_classes: int, offsets: Sequence[Tuple[int, int]],
+                    same_different_bias: float = 0.0, object_merge_factor: float = 1.0,
+                    merge_logprob_bias: float = 0.0, prune_threshold: float = 200.0) -> OracleResult:
+    lib = _load("libpysegmenter_oracle.so")
+    fn = lib.oracle_pysegmenter_run
+    fn.restype = ctypes.c_int
+    i64p = ctypes.POINTER(ctypes.c_longlong)
+    fn.argtypes = [_f64p, _f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
+                   ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                   i64p, _i32p, _i32p, _f64p]
+    cp, sp, off = _prep(class_probs, same_probs, offsets, dtype=np.float64)
+    C, H, W = cp.shape
+    if C != num_classes:
+        raise AssertionError("class_dim == num_classes (utils/segmenter.py:247)")
+    mask = np.zeros((H, W), np.int64)
+    table = np.zeros(H * W, np.int32)
+    part = np.zeros((H, W), np.int32)
+    stats = np.zeros(6, np.float64)
+    rc = fn(cp.ctypes.data_as(_f64p), sp.ctypes.data_as(_f64p), int(num_classes), sp.shape[0],
+            H, W, off.ctypes.data_as(_i32p), float(same_different_bias),
+            float(object_merge_factor), float(merge_logprob_bias), float(prune_threshold),
+            mask.ctypes.data_as(i64p), table.ctypes.data_as(_i32p), part.ctypes.data_as(_i32p),
+            stats.ctypes.data_as(_f64p))
+    if rc == -10:
+        raise PySegmenterError("NameError: no class-0 object to prune into (segmenter.py:356,365)")
+    if rc != 0:
+        raise PySegmenterError("oracle_pysegmenter_run failed with code %d" % rc)
+    classes = []
+    for v in table:
+        if v == -1:
+            break
+        classes.append(int(v))
+    names = ["total_logprob", "n_objects", "n_pops", "n_merges", "n_initial_records", "_"]
+    return OracleResult(mask, classes, part, float(stats[0]), dict(zip(names, stats.tolist())))

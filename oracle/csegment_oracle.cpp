@@ -80,7 +80,7 @@ struct Segmenter {
 
   std::priority_queue<std::pair<float, int>, std::vector<std::pair<float, int> >, ByPriority> pq;
 
-  long long n_pops = 0, n_merges = 0, n_rescored = 0;
+  long long n_pops = 0, n_merges = 0, n_rescored = 0, n_live_pops = 0;
 
   void rekey(int r) {
     if (r1[r] > r2[r]) std::swap(r1[r], r2[r]);
@@ -217,6 +217,7 @@ struct Segmenter {
       n_pops++;
       if (q != rprio[r]) continue;
       if (r2[r] < 0) continue;
+      n_live_pops++;
       rescore(r);
       if (rprio[r] == q) merge(r);
       else if (rprio[r] >= 0) pq.push(std::make_pair(rprio[r], r));
@@ -285,8 +286,8 @@ extern "C" {
 // plus optional outputs:
 //   partition[H*W]  surviving object id (= lowest-history survivor pixel id) per pixel,
 //                   BEFORE the class-0 collapse;
-//   stats[8]        {total_logprob, n_objects, n_pops, n_merges, t_build_s, t_loop_s,
-//                    n_rescored, n_initial_records}.
+//   stats[10]       {total_logprob, n_objects, n_pops, n_merges, t_build_s, t_loop_s,
+//                    n_rescored, n_initial_records, n_live_pops, 0}.
 // Returns 0, or a negative code for invalid arguments (the reference would crash/exit).
 int oracle_csegment_run(float* class_pred, int class_dim, float* adj_pred, int offset_dim,
                         int img_width, int img_height, int num_classes, const int* offset_list,
@@ -325,6 +326,8 @@ int oracle_csegment_run(float* class_pred, int class_dim, float* adj_pred, int o
     stats[5] = t2 - t1;
     stats[6] = (double)s.n_rescored;
     stats[7] = (double)n_rec;
+    stats[8] = (double)s.n_live_pops;
+    stats[9] = 0;
   }
   return 0;
 }
