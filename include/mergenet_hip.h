@@ -1,0 +1,155 @@
+/* mergenet_hip.h -- C ABI of libmergenet_hip.so (MI355X / gfx950 pixel merger).
+ *
+ * Drop-in boundary for the MergeNet post-processor (the greedy merger that folds pixels into
+ * instances by log-likelihood gain).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   c_run_segmentation      utils/csegment/segment.cc:742-765 (declared to Cython at
+ *                           utils/csegment/c_segment.pyx:16-25)  -- same symbol, same signature
+ *   ObjectSegmenterOption   utils/csegment/segment.h:245-268     -- mn_options (3 floats + mode)
+ *   ObjectSegmenter ctor    utils/csegment/segment.cc:153-232    -- phase A (affinity scoring)
+ *   RunSegmentation/Merge   utils/csegment/segment.cc:539-727    -- phase B (merge)
+ *   OutputMask              utils/csegment/segment.cc:491-517    -- label / class-table output
+ *   ObjectSegmenter (py)    utils/segmenter.py:225-483           -- MN_VARIANT_PYSEGMENTER
+ *
+ * Error behaviour: the reference returns void and calls exit(1) on internal inconsistencies
+ * (segment.cc:39-43,96-100,665-673).  Here every entry point except the ABI-compatible
+ * c_run_segmentation returns an int status (0 = MN_OK) and never exits; c_run_segmentation
+ * keeps the void signature, prints the failure to stderr and leaves mn_last_status() set.
+ *
+ * Threading: an mn_context owns one GPU workspace and is used by one thread at a time; separate
+ * contexts are independent (one per GPU / per process in the multi-GPU driver).
+ */
+#ifndef MERGENET_HIP_H_
+#define MERGENET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_MAX_OFFSETS 32
+#define MN_MAX_CLASSES 127
+
+enum mn_status {
+  MN_OK = 0,
+  MN_ERR_ARGUMENT = -1,     /* null pointer, non-positive size, class_dim < num_classes, ...  */
+  MN_ERR_OFFSETS = -2,      /* (0,0), a duplicate, or an offset together with its negation    */
+  MN_ERR_NO_DEVICE = -3,    /* no usable HIP device / HIP call failed (message on stderr)     */
+  MN_ERR_CAPACITY = -4,     /* image larger than the context was created for                  */
+  MN_ERR_NO_BACKGROUND = -10, /* pysegmenter prune: no class-0 object (reference: NameError)  */
+  MN_ERR_INTERNAL = -20
+};
+
+enum mn_variant {
+  MN_VARIANT_CSEGMENT = 0,    /* utils/csegment semantics: den = n1+n2, bias outside, merge on == */
+  MN_VARIANT_PYSEGMENTER = 1  /* utils/segmenter.py: den = n1*n2, bias inside, merge on >=, prune */
+};
+
+enum mn_mode {
+  MN_MODE_AUTO = 0,      /* exact when the image has <= exact_limit initial records, else rounds */
+  MN_MODE_EXACT = 1,     /* sequential lazy-greedy order on the GPU (one workgroup)              */
+  MN_MODE_ROUNDS = 2     /* parallel rounds + sequential finisher + certificate                  */
+};
+
+typedef struct mn_options {
+  float same_different_bias;   /* segment.h:246 */
+  float object_merge_factor;   /* segment.h:247 */
+  float merge_logprob_bias;    /* segment.h:248 */
+  int variant;                 /* enum mn_variant */
+  int mode;                    /* enum mn_mode */
+  int clip_inputs;             /* 1: clip to [2^-23, 1-2^-23] on load (c_segment.pyx:53-55 fused) */
+  int exact_limit;             /* AUTO: max initial records for exact mode (0 = default 32768)   */
+  int finish_limit;            /* ROUNDS: hand over to the sequential finisher at <= this many
+                                  live records (0 = default 8192)                               */
+  int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 8)          */
+  float prune_threshold;       /* pysegmenter prune threshold (segmenter.py:351; default 200)    */
+  int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) */
+  int reserved[4];
+} mn_options;
+
+typedef struct mn_stats {
+  int status;
+  int mode_used;               /* MN_MODE_EXACT or MN_MODE_ROUNDS */
+  int certified;               /* 1: result proven equal to the sequential reference partition
+                                  (sign-separable input, see DESIGN.md "certificate")           */
+  int num_instances;           /* labels 1..K written to the mask */
+  int num_objects;             /* surviving objects including class-0 ones */
+  int rounds;                  /* parallel rounds executed */
+  int finisher_steps;          /* sequential steps (pops) executed by the finisher */
+  int reserved_i;
+  long long initial_records;   /* in-bounds (pixel, offset) pairs */
+  long long merges;            /* objects absorbed */
+  double total_logprob;        /* A.4: sum lp[cls] + omf*(sum log p | log(1-p)); NaN if not asked */
+  float ms_score;              /* phase A kernels (class pass + edge pass), HIP events */
+  float ms_class_pass;
+  float ms_edge_pass;
+  float ms_merge;              /* phase B */
+  float ms_output;             /* labels, mask, class table, certificate, log-likelihood */
+  float ms_total;
+} mn_stats;
+
+typedef struct mn_context mn_context;
+
+/* Fill `o` with the Cityscapes caller's options (egs/cityscape/local/segment.py:134-136):
+ * same_different_bias 0, object_merge_factor 1, merge_logprob_bias 0.03, csegment, AUTO. */
+void mn_default_options(mn_options* o);
+
+/* Create a context on HIP device `device` able to hold images up to max_height x max_width with
+ * up to max_classes class planes and max_offsets offsets.  All device memory is allocated here;
+ * mn_segment_device allocates nothing.  Returns NULL on failure (see mn_last_status). */
+mn_context* mn_create(int device, int max_height, int max_width, int max_classes, int max_offsets);
+void mn_destroy(mn_context* ctx);
+size_t mn_workspace_bytes(const mn_context* ctx);
+
+/* Segment one image whose probability maps are ALREADY ON THE DEVICE.
+ *   d_class_pred [class_dim][H][W] float32, d_adj_pred [offset_dim][H][W] float32 (C order)
+ *   offset_list  HOST pointer, [offset_dim][2] = (d_row, d_col)   (segment.cc:166-169)
+ *   d_mask       [H][W] int32 out: 0 = every class-0 object, 1..K instances (segment.cc:491-517)
+ *   d_object_class [H*W] int32 out: class of label k at k-1, -1 from index K on
+ *   d_partition  optional [H*W] int32 out: surviving object id per pixel before the class-0
+ *                collapse (may be NULL)
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  The call enqueues work and
+ * synchronises the stream before returning when `stats` is non-NULL or the mode needs host
+ * decisions (ROUNDS does, per round).  Inputs are never modified (the reference rewrites
+ * adj_pred in place when same_different_bias != 0; here the bias is applied on load). */
+int mn_segment_device(mn_context* ctx, const float* d_class_pred, int class_dim,
+                      const float* d_adj_pred, int offset_dim, int img_width, int img_height,
+                      int num_classes, const int* offset_list, int* d_mask, int* d_object_class,
+                      int* d_partition, const mn_options* opts, void* stream, mn_stats* stats);
+
+/* Phase A alone (per-pixel class log-probs + argmax, per-edge log-odds and initial priorities,
+ * best initial record per pixel).  Used by bench.py / profiles to time the affinity-scoring pass
+ * against the HBM roofline, and by tests to compare phase-A arrays with the oracle.
+ *   d_cls_out   [H*W] uint8  argmax class per pixel                     (segment.cc:18-20)
+ *   d_best_out  [H*W] uint64 (priority bits << 32 | ~partner pixel id), 0 = no record >= 0 */
+int mn_score_device(mn_context* ctx, const float* d_class_pred, int class_dim,
+                    const float* d_adj_pred, int offset_dim, int img_width, int img_height,
+                    int num_classes, const int* offset_list, const mn_options* opts, void* stream,
+                    unsigned char* d_cls_out, unsigned long long* d_best_out, float* ms_class_pass,
+                    float* ms_edge_pass);
+
+/* Host-pointer convenience: copies in, runs mn_segment_device, copies out. */
+int mn_segment_host(mn_context* ctx, const float* class_pred, int class_dim, const float* adj_pred,
+                    int offset_dim, int img_width, int img_height, int num_classes,
+                    const int* offset_list, int* mask, int* object_class, int* partition,
+                    const mn_options* opts, mn_stats* stats);
+
+/* ABI-compatible replacement of the reference entry point (utils/csegment/segment.cc:742-754).
+ * Width precedes height.  Host pointers; inputs must already be clipped as the reference binding
+ * does (c_segment.pyx:53-55).  Unlike the reference it does not rewrite adj_pred. */
+void c_run_segmentation(float* class_pred, int class_dim, float* adj_pred, int offset_dim,
+                        int img_width, int img_height, int num_classes, int* offset_list,
+                        int* output, int* object_class, float same_different_bias,
+                        float object_merge_factor, float merge_logprob_bias);
+
+int mn_last_status(void);
+const char* mn_status_string(int status);
+const char* mn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERGENET_HIP_H_ */

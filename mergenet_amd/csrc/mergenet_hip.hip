@@ -1,0 +1,567 @@
+// mergenet_hip.hip -- host side of libmergenet_hip.so: workspace, launch sequence, C ABI.
+//
+// gfx950 only.  Build: see mergenet_amd/csrc/Makefile (hipcc --offload-arch=gfx950
+// -ffp-contract=off).  The entry points and the reference interfaces they replace are
+// documented in include/mergenet_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/mergenet_hip.h"
+#include "mn_device.h"
+#include "mn_kernels_score.h"
+#include "mn_kernels_merge.h"
+#include "mn_kernels_finish.h"
+#include "mn_kernels_output.h"
+
+static thread_local int g_last_status = MN_OK;
+
+#define MN_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      fprintf(stderr, "mergenet_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+              __FILE__, __LINE__);                                                        \
+      g_last_status = MN_ERR_NO_DEVICE;                                                   \
+      return MN_ERR_NO_DEVICE;                                                            \
+    }                                                                                     \
+  } while (0)
+
+struct mn_context {
+  int device;
+  int maxH, maxW, maxC, maxO;
+  size_t N, Rmax, cap;
+  size_t bytes;
+  // objects
+  unsigned char *ocls, *cls0, *lpvalid, *matched, *pruned;
+  int *osize, *parent, *mate, *root, *label, *mapbuf;
+  float* lpsum;
+  u64 *ball, *bsub;
+  // records
+  RecList LA, LB;
+  float* fresh;
+  unsigned char *aux, *sel;
+  int* touched_list;
+  HashTab T;
+  // output / scratch
+  int* block_count;
+  double* partial;
+  Counters* cnt;          // device
+  int* scalars;           // device: [0] violations, [1] total instances, [2] n_objects
+  u64* bg_key;            // device
+  double* lp_out;         // device [4]
+  Counters* h_cnt;        // pinned host mirror
+  int* h_scalars;         // pinned
+  double* h_lp;           // pinned
+  hipEvent_t ev[6];
+  // staging for the host-pointer entry points
+  float *d_class, *d_same;
+  int *d_mask, *d_objcls, *d_part;
+};
+
+static size_t next_pow2(size_t x) {
+  size_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+template <typename T>
+static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
+  const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
+  c->bytes += b;
+  return hipMalloc(reinterpret_cast<void**>(p), b);
+}
+
+extern "C" void mn_default_options(mn_options* o) {
+  memset(o, 0, sizeof(*o));
+  o->same_different_bias = 0.0f;
+  o->object_merge_factor = 1.0f;
+  o->merge_logprob_bias = 0.03f;
+  o->variant = MN_VARIANT_CSEGMENT;
+  o->mode = MN_MODE_AUTO;
+  o->clip_inputs = 0;
+  o->exact_limit = 0;
+  o->finish_limit = 0;
+  o->subrounds = 0;
+  o->prune_threshold = 200.0f;
+  o->compute_logprob = 1;
+}
+
+extern "C" int mn_last_status(void) { return g_last_status; }
+
+extern "C" const char* mn_status_string(int s) {
+  switch (s) {
+    case MN_OK: return "ok";
+    case MN_ERR_ARGUMENT: return "invalid argument";
+    case MN_ERR_OFFSETS: return "offset list holds (0,0), a duplicate, or an offset with its negation";
+    case MN_ERR_NO_DEVICE: return "HIP device unavailable or HIP call failed";
+    case MN_ERR_CAPACITY: return "image exceeds the context's capacity";
+    case MN_ERR_NO_BACKGROUND: return "prune: no class-0 object to merge into";
+    case MN_ERR_INTERNAL: return "internal error";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char* mn_version(void) { return "mergenet_hip 0.1 (gfx950)"; }
+
+static int ctx_alloc(mn_context* c) {
+  const size_t N = c->N, R = c->Rmax, cap = c->cap;
+  MN_HIP(dev_alloc(c, &c->ocls, N));
+  MN_HIP(dev_alloc(c, &c->cls0, N));
+  MN_HIP(dev_alloc(c, &c->lpvalid, N));
+  MN_HIP(dev_alloc(c, &c->matched, N));
+  MN_HIP(dev_alloc(c, &c->pruned, N));
+  MN_HIP(dev_alloc(c, &c->osize, N));
+  MN_HIP(dev_alloc(c, &c->parent, N));
+  MN_HIP(dev_alloc(c, &c->mate, N));
+  MN_HIP(dev_alloc(c, &c->root, N));
+  MN_HIP(dev_alloc(c, &c->label, N));
+  MN_HIP(dev_alloc(c, &c->mapbuf, N));
+  MN_HIP(dev_alloc(c, &c->lpsum, N * (size_t)c->maxC));
+  MN_HIP(dev_alloc(c, &c->ball, N));
+  MN_HIP(dev_alloc(c, &c->bsub, N));
+  MN_HIP(dev_alloc(c, &c->LA.key, R));
+  MN_HIP(dev_alloc(c, &c->LA.S, R));
+  MN_HIP(dev_alloc(c, &c->LA.st, R));
+  MN_HIP(dev_alloc(c, &c->LB.key, R));
+  MN_HIP(dev_alloc(c, &c->LB.S, R));
+  MN_HIP(dev_alloc(c, &c->LB.st, R));
+  MN_HIP(dev_alloc(c, &c->fresh, R));
+  MN_HIP(dev_alloc(c, &c->aux, R));
+  MN_HIP(dev_alloc(c, &c->sel, R));
+  MN_HIP(dev_alloc(c, &c->touched_list, R));
+  MN_HIP(dev_alloc(c, &c->T.key, cap));
+  MN_HIP(dev_alloc(c, &c->T.S, cap));
+  MN_HIP(dev_alloc(c, &c->T.st, cap));
+  MN_HIP(dev_alloc(c, &c->T.touched, cap));
+  MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
+  MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
+  MN_HIP(dev_alloc(c, &c->cnt, 1));
+  MN_HIP(dev_alloc(c, &c->scalars, 8));
+  MN_HIP(dev_alloc(c, &c->bg_key, 1));
+  MN_HIP(dev_alloc(c, &c->lp_out, 4));
+  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cnt), sizeof(Counters)));
+  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 8 * sizeof(int)));
+  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_lp), 4 * sizeof(double)));
+  for (int i = 0; i < 6; i++) MN_HIP(hipEventCreate(&c->ev[i]));
+  return MN_OK;
+}
+
+extern "C" mn_context* mn_create(int device, int max_height, int max_width, int max_classes,
+                                 int max_offsets) {
+  if (max_height <= 0 || max_width <= 0 || max_classes <= 0 || max_classes > MN_MAX_CLASSES ||
+      max_offsets <= 0 || max_offsets > MN_MAX_OFFSETS ||
+      (long long)max_height * max_width > (1LL << 28)) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return NULL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    fprintf(stderr, "mergenet_hip: no HIP device %d (found %d)\n", device, ndev);
+    g_last_status = MN_ERR_NO_DEVICE;
+    return NULL;
+  }
+  if (hipSetDevice(device) != hipSuccess) { g_last_status = MN_ERR_NO_DEVICE; return NULL; }
+  mn_context* c = static_cast<mn_context*>(calloc(1, sizeof(mn_context)));
+  if (!c) { g_last_status = MN_ERR_INTERNAL; return NULL; }
+  c->device = device;
+  c->maxH = max_height; c->maxW = max_width; c->maxC = max_classes; c->maxO = max_offsets;
+  c->N = (size_t)max_height * max_width;
+  c->Rmax = c->N * (size_t)max_offsets;
+  c->cap = next_pow2(c->Rmax + c->Rmax / 4 + 1024);
+  if (ctx_alloc(c) != MN_OK) { mn_destroy(c); return NULL; }
+  g_last_status = MN_OK;
+  return c;
+}
+
+extern "C" void mn_destroy(mn_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
+                 c->label, c->mapbuf, c->lpsum, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
+                 c->LB.key, c->LB.S, c->LB.st, c->fresh, c->aux, c->sel, c->touched_list, c->T.key,
+                 c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
+                 c->bg_key, c->lp_out, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
+  for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
+    if (dev[i]) (void)hipFree(dev[i]);
+  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  if (c->h_lp) (void)hipHostFree(c->h_lp);
+  for (int i = 0; i < 6; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  free(c);
+}
+
+extern "C" size_t mn_workspace_bytes(const mn_context* c) { return c ? c->bytes : 0; }
+
+// ---- argument checking shared by the entry points ---------------------------------------------
+static int check_args(const mn_context* c, int class_dim, int offset_dim, int W, int H,
+                      int num_classes, const int* offs, const mn_options* o) {
+  if (!c || !offs || !o) return MN_ERR_ARGUMENT;
+  if (W <= 0 || H <= 0 || num_classes <= 0 || offset_dim <= 0 || class_dim < num_classes)
+    return MN_ERR_ARGUMENT;
+  if (num_classes > MN_MAX_CLASSES || offset_dim > MN_MAX_OFFSETS) return MN_ERR_ARGUMENT;
+  if ((size_t)W * H > c->N || num_classes > c->maxC || offset_dim > c->maxO) return MN_ERR_CAPACITY;
+  if (o->variant != MN_VARIANT_CSEGMENT && o->variant != MN_VARIANT_PYSEGMENTER)
+    return MN_ERR_ARGUMENT;
+  for (int a = 0; a < offset_dim; a++)
+    for (int b = 0; b < offset_dim; b++) {
+      const bool neg = offs[2 * a] == -offs[2 * b] && offs[2 * a + 1] == -offs[2 * b + 1];
+      const bool dup = a != b && offs[2 * a] == offs[2 * b] && offs[2 * a + 1] == offs[2 * b + 1];
+      if (neg || dup) return MN_ERR_OFFSETS;   // also rejects (0,0): it is its own negation
+    }
+  return MN_OK;
+}
+
+static void fill_params(ImgParams* P, const float* d_class, const float* d_same, int offset_dim,
+                        int W, int H, int num_classes, const int* offs, const mn_options* o) {
+  memset(P, 0, sizeof(*P));
+  P->H = H; P->W = W; P->N = W * H; P->C = num_classes; P->O = offset_dim;
+  P->sdb = o->same_different_bias; P->omf = o->object_merge_factor; P->bias = o->merge_logprob_bias;
+  P->variant = o->variant; P->clip = o->clip_inputs ? 1 : 0;
+  P->cls = d_class; P->same = d_same;
+  for (int k = 0; k < offset_dim; k++) { P->di[k] = offs[2 * k]; P->dj[k] = offs[2 * k + 1]; }
+}
+
+static long long count_records(int W, int H, int offset_dim, const int* offs) {
+  long long r = 0;
+  for (int k = 0; k < offset_dim; k++) {
+    const long long hh = H - abs(offs[2 * k]), ww = W - abs(offs[2 * k + 1]);
+    if (hh > 0 && ww > 0) r += hh * ww;
+  }
+  return r;
+}
+
+static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+static ObjState obj_state(mn_context* c) {
+  ObjState S;
+  S.ocls = c->ocls; S.osize = c->osize; S.parent = c->parent; S.lpsum = c->lpsum;
+  S.lpvalid = c->lpvalid;
+  return S;
+}
+
+// phase A prologue + class pass (+ first edge pass when `edge` is set)
+static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge) {
+  const int N = P.N;
+  ObjState S = obj_state(c);
+  MN_HIP(hipMemsetAsync(c->lpvalid, 0, N, st));
+  MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
+  hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
+                     c->parent, c->mate);
+  MN_HIP(hipEventRecord(c->ev[0], st));
+  {
+    const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256);
+    hipLaunchKernelGGL(mn_class_pass, dim3(blocks), dim3(256), 0, st, P, c->ocls);
+  }
+  MN_HIP(hipEventRecord(c->ev[1], st));
+  if (edge) {
+    hipLaunchKernelGGL(mn_edge_pass<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
+                       (const unsigned char*)c->matched, c->ball);
+  }
+  MN_HIP(hipEventRecord(c->ev[2], st));
+  // the per-pixel arg-max is kept apart: ocls is overwritten as objects merge
+  MN_HIP(hipMemcpyAsync(c->cls0, c->ocls, N, hipMemcpyDeviceToDevice, st));
+  MN_HIP(hipGetLastError());
+  return MN_OK;
+}
+
+static int read_counters(mn_context* c, hipStream_t st) {
+  MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipStreamSynchronize(st));
+  return MN_OK;
+}
+
+static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t cap, RecList L,
+                      bool from_pixels, RecList src, int Rsrc, int* Rout) {
+  ObjState S = obj_state(c);
+  HashTab T = c->T;
+  T.mask = (unsigned)(cap - 1);
+  MN_HIP(hipMemsetAsync(T.key, 0xFF, cap * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(T.S, 0, cap * sizeof(i64), st));
+  MN_HIP(hipMemsetAsync(T.touched, 0, cap, st));
+  if (from_pixels)
+    hipLaunchKernelGGL(mn_build_from_pixels, dim3(grid_for(P.N, 256)), dim3(256), 0, st, P, S, T);
+  else
+    hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, 256)), dim3(256), 0, st, S, src, Rsrc, T);
+  MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
+  hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, 256)), dim3(256), 0, st, P, S, T, L, c->cnt);
+  MN_HIP(hipGetLastError());
+  if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
+  *Rout = c->h_cnt->n_records;
+  return MN_OK;
+}
+
+extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int class_dim,
+                                 const float* d_adj_pred, int offset_dim, int W, int H,
+                                 int num_classes, const int* offset_list, int* d_mask,
+                                 int* d_object_class, int* d_partition, const mn_options* opts,
+                                 void* stream, mn_stats* stats) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!d_class_pred || !d_adj_pred || !d_mask || !d_object_class)) rc = MN_ERR_ARGUMENT;
+  if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = rc; stats->total_logprob = NAN; }
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  ImgParams P;
+  fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  const int N = P.N;
+  const long long R0 = count_records(W, H, offset_dim, offset_list);
+  const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
+  const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 8192;
+  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 8;
+  int mode = opts->mode;
+  if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS)
+    mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_ROUNDS;
+  ObjState S = obj_state(c);
+
+  MN_HIP(hipMemsetAsync(c->cnt, 0, sizeof(Counters), st));
+  MN_HIP(hipMemsetAsync(c->scalars, 0, 8 * sizeof(int), st));
+  MN_HIP(hipMemsetAsync(c->mapbuf, 0xFF, (size_t)N * sizeof(int), st));
+
+  // ---------------- phase A ----------------
+  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS);
+  if (rc != MN_OK) return rc;
+
+  // ---------------- phase B ----------------
+  long long merges = 0;
+  int rounds = 0;
+  RecList cur = c->LA, nxt = c->LB;
+  int R = 0;
+  if (mode == MN_MODE_ROUNDS) {
+    // round 0 on the implicit pixel graph: matching sub-rounds, then one apply
+    hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
+                       (const u64*)c->ball, c->matched, c->mate);
+    for (int s = 1; s < subrounds; s++) {
+      hipLaunchKernelGGL(mn_edge_pass<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
+                         (const unsigned char*)c->matched, c->bsub);
+      hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
+                         (const u64*)c->bsub, c->matched, c->mate);
+    }
+    hipLaunchKernelGGL(mn_pix_apply, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
+                       (const int*)c->mate, c->cnt);
+    rounds = 1;
+  }
+  {
+    const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
+    rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
+    if (rc != MN_OK) return rc;
+    merges += c->h_cnt->n_merged;
+  }
+  if (mode == MN_MODE_ROUNDS) {
+    while (R > finish_limit && rounds < 5000) {
+      MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)N * sizeof(u64), st));
+      MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
+      MN_HIP(hipMemsetAsync(c->sel, 0, R, st));
+      MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records..n_selected
+      const dim3 g(grid_for(R, 256)), b(256);
+      hipLaunchKernelGGL(mn_rec_score, g, b, 0, st, P, S, cur, R, c->fresh, c->aux, c->ball, c->cnt);
+      hipLaunchKernelGGL(mn_rec_match, g, b, 0, st, cur, R, (const u64*)c->ball,
+                         (const unsigned char*)c->aux, 0, c->matched, c->sel);
+      for (int s = 1; s < subrounds; s++) {
+        MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));
+        hipLaunchKernelGGL(mn_rec_propose, g, b, 0, st, cur, R, (const unsigned char*)c->aux,
+                           (const unsigned char*)c->matched, c->bsub);
+        hipLaunchKernelGGL(mn_rec_match, g, b, 0, st, cur, R, (const u64*)c->bsub,
+                           (const unsigned char*)c->aux, 1, c->matched, c->sel);
+      }
+      hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
+                         (const unsigned char*)c->aux, (const unsigned char*)c->sel, c->cnt);
+      size_t cap = next_pow2((size_t)R * 2 + 1024);
+      if (cap > c->cap) cap = c->cap;
+      int Rn = 0;
+      rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn);
+      if (rc != MN_OK) return rc;
+      rounds++;
+      merges += c->h_cnt->n_merged;
+      const int selected = c->h_cnt->n_selected;
+      RecList t = cur; cur = nxt; nxt = t;
+      R = Rn;
+      if (selected == 0) break;     // nothing visible any more: the queue is empty
+    }
+  }
+  // sequential lazy-greedy on what is left (the whole problem in exact mode)
+  {
+    const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
+    MN_HIP(hipMemsetAsync(&c->cnt->n_merged, 0, sizeof(int), st));
+    hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
+                       c->touched_list, c->cnt, max_steps);
+  }
+  MN_HIP(hipEventRecord(c->ev[3], st));
+
+  // ---------------- output ----------------
+  hipLaunchKernelGGL(mn_roots, dim3(grid_for(N, 256)), dim3(256), 0, st, N, (const int*)c->parent,
+                     c->root);
+  const unsigned char* pruned = NULL;
+  if (opts->variant == MN_VARIANT_PYSEGMENTER) {
+    MN_HIP(hipMemsetAsync(c->bg_key, 0, sizeof(u64), st));
+    hipLaunchKernelGGL(mn_prune_find_background, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
+                       c->bg_key);
+    hipLaunchKernelGGL(mn_prune_mark, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
+                       opts->prune_threshold, (const u64*)c->bg_key, c->pruned, c->cnt);
+    pruned = c->pruned;
+  }
+  const int nblk = (int)grid_for(N, MN_SCAN_ITEMS);
+  hipLaunchKernelGGL(mn_rank_count, dim3(nblk), dim3(256), 0, st, N, S, pruned, c->block_count,
+                     c->scalars + 2);
+  hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 1);
+  MN_HIP(hipMemsetAsync(d_object_class, 0xFF, (size_t)N * sizeof(int), st));
+  hipLaunchKernelGGL(mn_rank_assign, dim3(nblk), dim3(256), 0, st, N, S, pruned,
+                     (const int*)c->block_count, c->label, d_object_class);
+  hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
+                     (const int*)c->root, (const int*)c->label, d_mask, d_partition);
+  // certificate + log-likelihood
+  {
+    const int vb = (int)grid_for(N, 256);
+    hipLaunchKernelGGL(mn_verify_edges, dim3(vb), dim3(256), 0, st, P, S,
+                       (const unsigned char*)c->cls0,
+                       (const int*)c->root, c->partial, c->scalars);
+    hipLaunchKernelGGL(mn_verify_reduce, dim3(1), dim3(256), 0, st, vb, (const double*)c->partial,
+                       P.omf, c->lp_out);
+    if (R > 0)
+      hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
+                         c->scalars);
+  }
+  MN_HIP(hipEventRecord(c->ev[4], st));
+  MN_HIP(hipGetLastError());
+
+  MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_lp, c->lp_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipStreamSynchronize(st));
+  merges += c->h_cnt->n_merged;
+  rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
+  if (stats) {
+    stats->status = rc;
+    stats->mode_used = mode;
+    const bool cert_opts = opts->object_merge_factor > 0.0f &&
+                           (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
+                                                                 : opts->merge_logprob_bias == 0.0f);
+    stats->certified = (c->h_scalars[0] == 0 && cert_opts) ? 1 : 0;
+    stats->num_instances = c->h_scalars[1];
+    stats->num_objects = c->h_scalars[2];
+    stats->rounds = rounds;
+    stats->finisher_steps = c->h_cnt->finisher_steps;
+    stats->initial_records = R0;
+    stats->merges = merges;
+    stats->total_logprob = c->h_lp[0];
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
+    hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
+    stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
+    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
+    hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
+    hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+  }
+  g_last_status = rc;
+  return rc;
+}
+
+extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int class_dim,
+                               const float* d_adj_pred, int offset_dim, int W, int H,
+                               int num_classes, const int* offset_list, const mn_options* opts,
+                               void* stream, unsigned char* d_cls_out,
+                               unsigned long long* d_best_out, float* ms_class_pass,
+                               float* ms_edge_pass) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!d_class_pred || !d_adj_pred)) rc = MN_ERR_ARGUMENT;
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ImgParams P;
+  fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  rc = run_phase_a(c, P, st, true);
+  if (rc != MN_OK) return rc;
+  if (d_cls_out) MN_HIP(hipMemcpyAsync(d_cls_out, c->ocls, P.N, hipMemcpyDeviceToDevice, st));
+  if (d_best_out)
+    MN_HIP(hipMemcpyAsync(d_best_out, c->ball, (size_t)P.N * sizeof(u64), hipMemcpyDeviceToDevice, st));
+  MN_HIP(hipStreamSynchronize(st));
+  float ms = 0;
+  hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+  if (ms_class_pass) *ms_class_pass = ms;
+  hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+  if (ms_edge_pass) *ms_edge_pass = ms;
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+static int ensure_staging(mn_context* c) {
+  if (c->d_class) return MN_OK;
+  MN_HIP(dev_alloc(c, &c->d_class, c->N * (size_t)c->maxC));
+  MN_HIP(dev_alloc(c, &c->d_same, c->N * (size_t)c->maxO));
+  MN_HIP(dev_alloc(c, &c->d_mask, c->N));
+  MN_HIP(dev_alloc(c, &c->d_objcls, c->N));
+  MN_HIP(dev_alloc(c, &c->d_part, c->N));
+  return MN_OK;
+}
+
+extern "C" int mn_segment_host(mn_context* c, const float* class_pred, int class_dim,
+                               const float* adj_pred, int offset_dim, int W, int H, int num_classes,
+                               const int* offset_list, int* mask, int* object_class, int* partition,
+                               const mn_options* opts, mn_stats* stats) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!class_pred || !adj_pred || !mask || !object_class)) rc = MN_ERR_ARGUMENT;
+  if (rc != MN_OK) { g_last_status = rc; if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = rc; } return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  rc = ensure_staging(c);
+  if (rc != MN_OK) return rc;
+  const size_t N = (size_t)W * H;
+  // only the first num_classes planes are used (class_dim == num_classes assumed by the reference)
+  MN_HIP(hipMemcpy(c->d_class, class_pred, N * num_classes * sizeof(float), hipMemcpyHostToDevice));
+  MN_HIP(hipMemcpy(c->d_same, adj_pred, N * offset_dim * sizeof(float), hipMemcpyHostToDevice));
+  rc = mn_segment_device(c, c->d_class, num_classes, c->d_same, offset_dim, W, H, num_classes,
+                         offset_list, c->d_mask, c->d_objcls, c->d_part, opts, NULL, stats);
+  if (rc != MN_OK && rc != MN_ERR_NO_BACKGROUND) return rc;
+  MN_HIP(hipMemcpy(mask, c->d_mask, N * sizeof(int), hipMemcpyDeviceToHost));
+  MN_HIP(hipMemcpy(object_class, c->d_objcls, N * sizeof(int), hipMemcpyDeviceToHost));
+  if (partition) MN_HIP(hipMemcpy(partition, c->d_part, N * sizeof(int), hipMemcpyDeviceToHost));
+  return rc;
+}
+
+// ABI-compatible entry (utils/csegment/segment.cc:742-754).  A context is cached per thread and
+// grown on demand; failures are reported on stderr and through mn_last_status().
+extern "C" void c_run_segmentation(float* class_pred, int class_dim, float* adj_pred, int offset_dim,
+                                   int img_width, int img_height, int num_classes, int* offset_list,
+                                   int* output, int* object_class, float same_different_bias,
+                                   float object_merge_factor, float merge_logprob_bias) {
+  static thread_local mn_context* cached = NULL;
+  if (img_width <= 0 || img_height <= 0 || num_classes <= 0 || offset_dim <= 0) {
+    g_last_status = MN_ERR_ARGUMENT;
+    fprintf(stderr, "c_run_segmentation: %s\n", mn_status_string(MN_ERR_ARGUMENT));
+    return;
+  }
+  if (cached && ((size_t)img_width * img_height > cached->N || num_classes > cached->maxC ||
+                 offset_dim > cached->maxO)) {
+    mn_destroy(cached);
+    cached = NULL;
+  }
+  if (!cached) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cached = mn_create(dev, img_height, img_width, num_classes, offset_dim);
+    if (!cached) {
+      fprintf(stderr, "c_run_segmentation: %s\n", mn_status_string(g_last_status));
+      return;
+    }
+  }
+  mn_options o;
+  mn_default_options(&o);
+  o.same_different_bias = same_different_bias;
+  o.object_merge_factor = object_merge_factor;
+  o.merge_logprob_bias = merge_logprob_bias;
+  o.compute_logprob = 0;
+  const int rc = mn_segment_host(cached, class_pred, class_dim, adj_pred, offset_dim, img_width,
+                                 img_height, num_classes, offset_list, output, object_class, NULL,
+                                 &o, NULL);
+  if (rc != MN_OK) fprintf(stderr, "c_run_segmentation: %s\n", mn_status_string(rc));
+}

@@ -1,0 +1,143 @@
+// mn_device.h -- device-side arithmetic shared by every kernel of libmergenet_hip.so.
+//
+// Written for gfx950 only (wave64).  All record arithmetic that decides a merge is float32
+// in the reference's operation order (utils/csegment/segment.cc:107-150) and this file is
+// compiled with -ffp-contract=off so that no multiply-add is fused behind our back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mergenet_hip.h"
+
+#define MN_EPS32 1.1920928955078125e-07f   /* 2^-23, np.finfo(np.float32).eps */
+#define MN_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define MN_FIX_ONE 1073741824.0             /* 2^30: fixed-point scale of log-odds sums */
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+struct ImgParams {
+  int H, W, N, C, O;
+  float sdb, omf, bias;
+  int variant, clip;
+  const float* cls;    // [C][N] class probabilities (borrowed)
+  const float* same;   // [O][N] sameness probabilities (borrowed)
+  int di[MN_MAX_OFFSETS];
+  int dj[MN_MAX_OFFSETS];
+};
+
+// Per-object state.  Object id = pixel id of the surviving pixel (segment.cc:197-206).
+// lpsum is filled lazily: an object that never merged reads its class log-probs straight
+// from the class planes (lpvalid == 0), so phase A never writes a [C][N] table.
+struct ObjState {
+  unsigned char* ocls;     // [N] current class            (Object::object_class)
+  int* osize;              // [N] pixel count              (Object::pixels.size())
+  int* parent;             // [N] absorbed -> survivor; self for live objects
+  float* lpsum;            // [C][N] summed class log-probs (Object::class_logprobs)
+  unsigned char* lpvalid;  // [N]
+};
+
+__device__ __forceinline__ float mn_clip(float v) {
+  return fminf(fmaxf(v, MN_EPS32), 1.0f - MN_EPS32);
+}
+
+// log(1 - v) in float32 without the cancellation of a plain 1.0f - v: d = fl(1 - v),
+// e = (1 - d) - v is the exact rounding residual (Fast2Sum, 1 >= v), log(d + e) ~ log d + e/d.
+// The reference computes (float)log(1.0 - (double)v) (segment.cc:34).
+__device__ __forceinline__ float mn_log1m(float v) {
+  const float d = 1.0f - v;
+  const float e = (1.0f - d) - v;
+  return logf(d) + e / d;
+}
+
+// same_different_bias applied on load instead of rewriting the plane (segment.cc:183-195).
+__device__ __forceinline__ float mn_same_value(const ImgParams& P, float v) {
+  if (P.clip) v = mn_clip(v);
+  if (P.sdb != 0.0f) {
+    const float logit = (logf(v) - mn_log1m(v)) + P.sdb;
+    v = 1.0f / (1.0f + expf(-logit));
+  }
+  return v;
+}
+
+__device__ __forceinline__ float mn_ld_class(const ImgParams& P, int c, int p) {
+  float v = P.cls[(size_t)c * P.N + p];
+  if (P.clip) v = mn_clip(v);
+  return v;
+}
+
+// log-odds of one edge (segment.cc:33-36), quantised to the fixed-point unit used for sums so
+// that every kernel sees the same value for the same edge.
+__device__ __forceinline__ i64 mn_edge_fixed(float v) {
+  const float oml = logf(v) - mn_log1m(v);
+  return __double2ll_rn((double)oml * MN_FIX_ONE);
+}
+__device__ __forceinline__ float mn_fixed_to_float(i64 s) {
+  return (float)((double)s * (1.0 / MN_FIX_ONE));
+}
+
+__device__ __forceinline__ float mn_obj_lp(const ImgParams& P, const ObjState& S, bool valid,
+                                           int obj, int c) {
+  return valid ? S.lpsum[(size_t)c * P.N + obj] : logf(mn_ld_class(P, c, obj));
+}
+
+// Priority of the record (u, v), u < v, with summed log-odds `oml`
+// (ComputeClassDeltaLogprob + UpdateMergePriority, segment.cc:107-150; the Python variant
+// utils/segmenter.py:179-193 differs in the denominator and in where the bias sits).
+// *gain_pos reports whether the likelihood gain itself (numerator without the bias) is > 0.
+__device__ __forceinline__ float mn_score(const ImgParams& P, const ObjState& S, int u, int v,
+                                          float oml, int* merged_cls, bool* gain_pos) {
+  const int cu = S.ocls[u], cv = S.ocls[v];
+  float cdl = 0.0f;
+  int mc = cu;
+  if (cu != cv) {
+    const bool vu = S.lpvalid[u] != 0, vv = S.lpvalid[v] != 0;
+    float best = 0.0f, lu = 0.0f, lv = 0.0f;
+    for (int c = 0; c < P.C; c++) {
+      const float a = mn_obj_lp(P, S, vu, u, c);
+      const float b = mn_obj_lp(P, S, vv, v, c);
+      const float j = a + b;
+      if (c == 0 || j > best) { best = j; mc = c; }
+      if (c == cu) lu = a;
+      if (c == cv) lv = b;
+    }
+    cdl = (best - lu) - lv;
+  }
+  *merged_cls = mc;
+  const int nu = S.osize[u], nv = S.osize[v];
+  const float num = oml * P.omf + cdl;
+  *gain_pos = num > 0.0f;
+  if (P.variant == MN_VARIANT_CSEGMENT) {
+    const float den = (float)(nu + nv);
+    return num / den + P.bias;
+  }
+  const float den = (float)nu * (float)nv;
+  return (num + P.bias) / den;
+}
+
+// (priority, partner) packed so that an unsigned max picks the highest priority and, among
+// equal priorities, the LOWEST partner id.  Only priorities >= 0 are packed.
+__device__ __forceinline__ u64 mn_pack(float prio, int partner) {
+  const unsigned bits = (prio == 0.0f) ? 0u : __float_as_uint(prio);
+  return ((u64)bits << 32) | (u64)(0xFFFFFFFFu - (unsigned)partner);
+}
+__device__ __forceinline__ int mn_pack_partner(u64 k) {
+  return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+}
+
+__device__ __forceinline__ u64 mn_key(int a, int b) {
+  const unsigned lo = (unsigned)min(a, b), hi = (unsigned)max(a, b);
+  return ((u64)lo << 32) | (u64)hi;
+}
+__device__ __forceinline__ int mn_key_u(u64 k) { return (int)(k >> 32); }
+__device__ __forceinline__ int mn_key_v(u64 k) { return (int)(k & 0xFFFFFFFFull); }
+
+__device__ __forceinline__ unsigned mn_hash(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (unsigned)k;
+}

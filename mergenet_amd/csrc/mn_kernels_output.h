@@ -1,0 +1,229 @@
+// mn_kernels_output.h -- labels, mask, class table, prune, certificate and log-likelihood.
+//
+// Reference work replaced:
+//   OutputMask                     utils/csegment/segment.cc:491-517   -> roots/rank/mask kernels
+//   prune + output_mask (Python)   utils/segmenter.py:351-389          -> mn_prune_* kernels
+//   ComputeTotalLogprobFromScratch utils/csegment/segment.cc:314-350   -> mn_verify_edges
+// Labels are handed out in ascending surviving object id (the reference uses hash-map iteration
+// order; results are compared up to a permutation of 1..K).
+#pragma once
+
+#include "mn_device.h"
+#include "mn_kernels_merge.h"
+
+#define MN_SCAN_ITEMS 1024   /* pixels per block in the label ranking */
+
+__global__ __launch_bounds__(256) void mn_roots(int N, const int* __restrict__ parent,
+                                                int* __restrict__ root) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  int r = p;
+  while (parent[r] != r) r = parent[r];
+  root[p] = r;
+}
+
+// ---- Python-variant prune (segmenter.py:351-375) ----------------------------------------------
+// background = class-0 object with the most pixels (first such in ascending id);
+// every other object with lp[cls] - lp[0] < threshold is dumped into it (label 0).
+__global__ __launch_bounds__(256) void mn_prune_find_background(ImgParams P, ObjState S,
+                                                                u64* __restrict__ bg_key) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N || S.parent[p] != p || S.ocls[p] != 0) return;
+  atomicMax(bg_key, ((u64)(unsigned)S.osize[p] << 32) | (u64)(0xFFFFFFFFu - (unsigned)p));
+}
+
+__global__ __launch_bounds__(256) void mn_prune_mark(ImgParams P, ObjState S, float threshold,
+                                                     const u64* __restrict__ bg_key,
+                                                     unsigned char* __restrict__ pruned,
+                                                     Counters* __restrict__ cnt) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  pruned[p] = 0;
+  if (S.parent[p] != p) return;
+  const bool valid = S.lpvalid[p] != 0;
+  const float score = mn_obj_lp(P, S, valid, p, S.ocls[p]) - mn_obj_lp(P, S, valid, p, 0);
+  if (!(score < threshold)) return;
+  const u64 k = *bg_key;
+  if (k == 0) { cnt->error = MN_ERR_NO_BACKGROUND; return; }   // reference: NameError
+  const int bg = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+  if (p != bg) pruned[p] = 1;
+}
+
+// ---- label ranking: instances are the live objects whose class is not 0 -----------------------
+__device__ __forceinline__ int mn_is_instance(const ObjState& S, const unsigned char* pruned, int p) {
+  return (S.parent[p] == p && S.ocls[p] != 0 && !(pruned && pruned[p])) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void mn_rank_count(int N, ObjState S,
+                                                     const unsigned char* __restrict__ pruned,
+                                                     int* __restrict__ block_count,
+                                                     int* __restrict__ n_objects) {
+  __shared__ int sh[4];
+  const int base = blockIdx.x * MN_SCAN_ITEMS;
+  int c = 0, live = 0;
+  for (int k = threadIdx.x; k < MN_SCAN_ITEMS; k += 256) {
+    const int p = base + k;
+    if (p < N) { c += mn_is_instance(S, pruned, p); live += (S.parent[p] == p) ? 1 : 0; }
+  }
+  for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); live += __shfl_xor(live, off); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = c; if (live) atomicAdd(n_objects, live); }
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// exclusive scan of the per-block counts by one workgroup; writes the total too
+__global__ __launch_bounds__(1024) void mn_rank_scan(int nblocks, int* __restrict__ block_count,
+                                                     int* __restrict__ total) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? block_count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_count[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// label[root] = rank + 1 in ascending id; object_class[rank] = class (segment.cc:509)
+__global__ __launch_bounds__(256) void mn_rank_assign(int N, ObjState S,
+                                                      const unsigned char* __restrict__ pruned,
+                                                      const int* __restrict__ block_offset,
+                                                      int* __restrict__ label,
+                                                      int* __restrict__ object_class) {
+  __shared__ int sh_w[4];
+  const int base = blockIdx.x * MN_SCAN_ITEMS;
+  int running = block_offset[blockIdx.x];
+  for (int k0 = 0; k0 < MN_SCAN_ITEMS; k0 += 256) {
+    const int p = base + k0 + threadIdx.x;
+    const int f = (p < N) ? mn_is_instance(S, pruned, p) : 0;
+    const u64 m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sh_w[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += sh_w[w];
+    const int tot = sh_w[0] + sh_w[1] + sh_w[2] + sh_w[3];
+    if (p < N) {
+      if (f) {
+        const int rank = running + woff + before;
+        label[p] = rank + 1;
+        object_class[rank] = S.ocls[p];
+      } else {
+        label[p] = 0;
+      }
+    }
+    running += tot;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void mn_write_mask(int N, const int* __restrict__ root,
+                                                     const int* __restrict__ label,
+                                                     int* __restrict__ mask,
+                                                     int* __restrict__ partition) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int r = root[p];
+  mask[p] = label[r];
+  if (partition) partition[p] = r;
+}
+
+// ---- certificate + log-likelihood over the pixel graph ----------------------------------------
+// One lane per pixel.  Sums (float64, reduced per block, combined in block order by
+// mn_verify_reduce so the result does not depend on scheduling):
+//   class term  log class[cls(obj(p))][p], sameness term log p over edges inside one object,
+//   differentness term log(1-p) over edges between objects          (segment.cc:314-350)
+// Violations of the sign-separability certificate: an edge inside an object whose
+// log-odds are not > 0, an edge between objects whose log-odds are not < 0, or a pixel whose own
+// arg-max class differs from its object's class.
+__global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
+                                                       const unsigned char* __restrict__ cls0,
+                                                       const int* __restrict__ root,
+                                                       double* __restrict__ partial,
+                                                       int* __restrict__ violations) {
+  __shared__ double sh[3][4];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double t_cls = 0.0, t_same = 0.0, t_diff = 0.0;
+  int bad = 0;
+  if (p < P.N) {
+    const int r = p / P.W, c = p - r * P.W;
+    const int ro = root[p];
+    const int oc = S.ocls[ro];
+    t_cls = (double)logf(mn_ld_class(P, oc, p));
+    if (cls0[p] != oc) bad++;
+    for (int k = 0; k < P.O; k++) {
+      const int rr = r + P.di[k], cc = c + P.dj[k];
+      if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
+      const int q = rr * P.W + cc;
+      const float v = mn_same_value(P, P.same[(size_t)k * P.N + p]);
+      const float ls = logf(v), ld = mn_log1m(v);
+      const float g = (ls - ld) * P.omf;
+      if (root[q] == ro) { t_same += (double)ls; if (!(g > 0.0f)) bad++; }
+      else               { t_diff += (double)ld; if (!(g < 0.0f)) bad++; }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    t_cls += __shfl_xor(t_cls, off);
+    t_same += __shfl_xor(t_same, off);
+    t_diff += __shfl_xor(t_diff, off);
+    bad += __shfl_xor(bad, off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wave] = t_cls; sh[1][wave] = t_same; sh[2][wave] = t_diff;
+    if (bad) atomicAdd(violations, bad);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(size_t)blockIdx.x * 3 + threadIdx.x] =
+        ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void mn_verify_reduce(int nblocks, const double* __restrict__ partial,
+                                                        float omf, double* __restrict__ out) {
+  __shared__ double sh[3][256];
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int j = 0; j < 3; j++) a[j] += partial[(size_t)b * 3 + j];
+  for (int j = 0; j < 3; j++) sh[j][threadIdx.x] = a[j];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int j = 0; j < 3; j++) sh[j][threadIdx.x] += sh[j][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sh[0][0] + (sh[2][0] + sh[1][0]) * (double)omf;
+    out[1] = sh[0][0]; out[2] = sh[1][0]; out[3] = sh[2][0];
+  }
+}
+
+// Quotient condition of the certificate: no record between two final objects may still be
+// mergeable (priority must be negative with a margin that covers float32 accumulation).
+__global__ __launch_bounds__(256) void mn_verify_records(ImgParams P, ObjState S, RecList L, int R,
+                                                         int* __restrict__ violations) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const u64 key = L.key[i];
+  if (key == MN_EMPTY) return;
+  int mc;
+  bool pos;
+  const float oml = mn_fixed_to_float(L.S[i]);
+  const float f = mn_score(P, S, mn_key_u(key), mn_key_v(key), oml, &mc, &pos);
+  const float margin = 1e-6f + 1e-5f * fabsf(P.bias);
+  if (!(f < -margin)) atomicAdd(violations, 1);
+}

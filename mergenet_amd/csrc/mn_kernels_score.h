@@ -1,0 +1,95 @@
+// mn_kernels_score.h -- phase A, the affinity-scoring pass (HBM-bound; roofline-judged).
+//
+// Reference work replaced: ObjectSegmenter::ObjectSegmenter (utils/csegment/segment.cc:153-232):
+//   HOT LOOP 1 (:198-207)  per pixel C x logf + first-max argmax      -> mn_class_pass
+//   HOT LOOP 2 (:209-231)  per in-bounds (pixel, offset): logf(p), log(1-p), log-odds,
+//                          class delta, initial priority, heap push if >= 0 -> mn_edge_pass
+// Instead of materialising 20.7 M records and a heap, the edge pass consumes every score on
+// the fly and keeps, per pixel, only the best incident record (priority, partner): that is the
+// first selection step of the merge phase.  Algorithmic HBM reads: 4*(C+O) bytes per pixel.
+#pragma once
+
+#include "mn_device.h"
+
+// ---- class pass: cls[p] = first-max argmax_c logf(class[c][p]) -------------------------------
+// 4 consecutive pixels per lane (16-byte loads, 1 KiB per wave-instruction); planes are
+// [C][N] so consecutive lanes read consecutive addresses of one plane.
+__global__ __launch_bounds__(256) void mn_class_pass(ImgParams P, unsigned char* __restrict__ cls_out) {
+  const int n4 = P.N >> 2;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 best;
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    for (int c = 0; c < P.C; c++) {
+      float4 v = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)i);
+      if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
+      float4 l;
+      l.x = logf(v.x); l.y = logf(v.y); l.z = logf(v.z); l.w = logf(v.w);
+      if (c == 0) {
+        best = l;
+      } else {
+        if (l.x > best.x) { best.x = l.x; b0 = c; }
+        if (l.y > best.y) { best.y = l.y; b1 = c; }
+        if (l.z > best.z) { best.z = l.z; b2 = c; }
+        if (l.w > best.w) { best.w = l.w; b3 = c; }
+      }
+    }
+    uchar4 o;
+    o.x = (unsigned char)b0; o.y = (unsigned char)b1; o.z = (unsigned char)b2; o.w = (unsigned char)b3;
+    *reinterpret_cast<uchar4*>(cls_out + 4 * (size_t)i) = o;
+  }
+  // tail pixels when N is not a multiple of 4
+  const int tail0 = n4 << 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < P.N - tail0) {
+    const int p = tail0 + t;
+    float best = 0.0f;
+    int b = 0;
+    for (int c = 0; c < P.C; c++) {
+      const float l = logf(mn_ld_class(P, c, p));
+      if (c == 0 || l > best) { best = l; b = c; }
+    }
+    cls_out[p] = (unsigned char)b;
+  }
+}
+
+// ---- edge pass: best incident record per pixel ------------------------------------------------
+// One lane per pixel; a wave covers 64 consecutive columns of one row, so each of the 2*O
+// sameness loads (own value for the outgoing edge, the neighbour's value for the incoming one)
+// is a coalesced row segment shifted by a constant.  FIRST = true scores every edge (round 0,
+// sub-round 0).  FIRST = false is a later matching sub-round: only edges between two still
+// unmatched pixels with positive likelihood gain compete.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void mn_edge_pass(ImgParams P, ObjState S,
+                                                    const unsigned char* __restrict__ matched,
+                                                    u64* __restrict__ best_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  if (!FIRST && matched[p]) { best_out[p] = 0; return; }
+  const int r = p / P.W, c = p - r * P.W;
+  u64 best = 0;
+  for (int k = 0; k < P.O; k++) {
+    const int di = P.di[k], dj = P.dj[k];
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      // dir 0: outgoing edge p -> q = p + o_k, value stored at p
+      // dir 1: incoming edge q = p - o_k -> p, value stored at q
+      const int rr = dir ? r - di : r + di;
+      const int cc = dir ? c - dj : c + dj;
+      if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
+      const int q = rr * P.W + cc;
+      if (!FIRST && matched[q]) continue;
+      const int src = dir ? q : p;
+      const float v = mn_same_value(P, P.same[(size_t)k * P.N + src]);
+      const float oml = mn_fixed_to_float(mn_edge_fixed(v));
+      int mc;
+      bool pos;
+      const float prio = mn_score(P, S, min(p, q), max(p, q), oml, &mc, &pos);
+      if (!(prio >= 0.0f)) continue;
+      if (!FIRST && !pos) continue;
+      const u64 key = mn_pack(prio, q);
+      best = key > best ? key : best;
+    }
+  }
+  best_out[p] = best;
+}

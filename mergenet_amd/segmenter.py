@@ -1,0 +1,373 @@
+"""Host-side mirror of the reference merger interfaces, bound to libmergenet_hip.so over ctypes.
+
+Same names, argument meaning and error behaviour as the reference for this path:
+
+* :func:`run_segmentation` -- the Cython binding ``utils/csegment/c_segment.pyx:30-86``
+  (typed-buffer checks, clip to ``[eps32, 1-eps32]``, int32 offset array, output allocation,
+  ``-1``-terminated class table read over ``range(H*W-1)``), calling the ABI-compatible
+  ``c_run_segmentation`` (``utils/csegment/segment.cc:742-754``) of the HIP library.
+* :class:`SegmenterOptions`, :class:`ObjectSegmenter` -- ``utils/segmenter.py:21-24,225-483``
+  (Python-variant semantics: ``n1*n2`` denominator, bias inside, merge on ``>=``, ``prune``).
+* :class:`Merger` -- device-resident API for PyTorch-ROCm callers (tensors in, tensors out,
+  current HIP stream); PyTorch is only used for memory and streams.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible the calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from collections import namedtuple
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmergenet_hip.so")
+
+MN_VARIANT_CSEGMENT = 0
+MN_VARIANT_PYSEGMENTER = 1
+MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS = 0, 1, 2
+MN_ERR_NO_BACKGROUND = -10
+
+SegmenterOptions = namedtuple("SegmenterOptions",
+                              ["same_different_bias", "object_merge_factor", "merge_logprob_bias"])
+
+
+class MnOptions(ctypes.Structure):
+    _fields_ = [("same_different_bias", ctypes.c_float), ("object_merge_factor", ctypes.c_float),
+                ("merge_logprob_bias", ctypes.c_float), ("variant", ctypes.c_int),
+                ("mode", ctypes.c_int), ("clip_inputs", ctypes.c_int),
+                ("exact_limit", ctypes.c_int), ("finish_limit", ctypes.c_int),
+                ("subrounds", ctypes.c_int), ("prune_threshold", ctypes.c_float),
+                ("compute_logprob", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
+
+
+class MnStats(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("mode_used", ctypes.c_int), ("certified", ctypes.c_int),
+                ("num_instances", ctypes.c_int), ("num_objects", ctypes.c_int),
+                ("rounds", ctypes.c_int), ("finisher_steps", ctypes.c_int),
+                ("reserved_i", ctypes.c_int), ("initial_records", ctypes.c_longlong),
+                ("merges", ctypes.c_longlong), ("total_logprob", ctypes.c_double),
+                ("ms_score", ctypes.c_float), ("ms_class_pass", ctypes.c_float),
+                ("ms_edge_pass", ctypes.c_float), ("ms_merge", ctypes.c_float),
+                ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}
+
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+_lib_handle = None
+
+EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
+           "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
+           "mn_last_status", "mn_status_string", "mn_version"]
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libmergenet_hip.so (built in-tree by ``__graft_entry__.build``); fail loudly."""
+    global _lib_handle
+    if _lib_handle is not None:
+        return _lib_handle
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build() / make -C "
+                           "mergenet_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mn_default_options.argtypes = [ctypes.POINTER(MnOptions)]
+    lib.mn_default_options.restype = None
+    lib.mn_create.argtypes = [ctypes.c_int] * 5
+    lib.mn_create.restype = ctypes.c_void_p
+    lib.mn_destroy.argtypes = [ctypes.c_void_p]
+    lib.mn_destroy.restype = None
+    lib.mn_workspace_bytes.argtypes = [ctypes.c_void_p]
+    lib.mn_workspace_bytes.restype = ctypes.c_size_t
+    lib.mn_segment_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, _i32p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.POINTER(MnOptions), ctypes.c_void_p,
+                                      ctypes.POINTER(MnStats)]
+    lib.mn_segment_device.restype = ctypes.c_int
+    lib.mn_score_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
+                                    ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, _f32p, _f32p]
+    lib.mn_score_device.restype = ctypes.c_int
+    lib.mn_segment_host.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p,
+                                    _i32p, ctypes.POINTER(MnOptions), ctypes.POINTER(MnStats)]
+    lib.mn_segment_host.restype = ctypes.c_int
+    lib.c_run_segmentation.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_float]
+    lib.c_run_segmentation.restype = None
+    lib.mn_last_status.restype = ctypes.c_int
+    lib.mn_status_string.argtypes = [ctypes.c_int]
+    lib.mn_status_string.restype = ctypes.c_char_p
+    lib.mn_version.restype = ctypes.c_char_p
+    _lib_handle = lib
+    return lib
+
+
+class MergeNetError(RuntimeError):
+    def __init__(self, status: int):
+        lib = load_library()
+        super().__init__("mergenet_hip status %d: %s" % (status, lib.mn_status_string(status).decode()))
+        self.status = status
+
+
+def default_options(**overrides) -> MnOptions:
+    o = MnOptions()
+    load_library().mn_default_options(ctypes.byref(o))
+    for k, v in overrides.items():
+        setattr(o, k, v)
+    return o
+
+
+def _class_list(table: np.ndarray) -> List[int]:
+    out = []
+    for i in range(table.shape[0] - 1):       # c_segment.pyx:80-84
+        if table[i] == -1:
+            break
+        out.append(int(table[i]))
+    return out
+
+
+def _check_buffer(name: str, a) -> np.ndarray:
+    """The typed-buffer contract of c_segment.pyx:30-31 (float32, ndim 3, C-contiguous)."""
+    if a is None:
+        raise TypeError("Argument '%s' must not be None" % name)
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.dtype != np.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float' but got '%s'" % a.dtype)
+    if a.ndim != 3:
+        raise ValueError("Buffer has wrong number of dimensions (expected 3, got %d)" % a.ndim)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("ndarray is not C-contiguous")
+    return a
+
+
+def run_segmentation(class_pred, adj_pred, num_classes: int, offset_list,
+                     same_different_bias: float, object_merge_factor: float,
+                     merge_logprob_bias: float):
+    """Drop-in for ``csegment.c_segment.run_segmentation`` (c_segment.pyx:30-86).
+
+    Returns ``(mask int32[H, W], object_class list)``; label 0 = every class-0 object.
+    """
+    class_pred = _check_buffer("class_pred", class_pred)
+    adj_pred = _check_buffer("adj_pred", adj_pred)
+    if offset_list is None or not isinstance(offset_list, list):
+        raise TypeError("Argument 'offset_list' has incorrect type (expected list)")
+    epsilon = np.finfo(np.float32).eps
+    class_pred = np.ascontiguousarray(class_pred.clip(epsilon, 1.0 - epsilon), dtype=np.float32)
+    adj_pred = np.ascontiguousarray(adj_pred.clip(epsilon, 1.0 - epsilon), dtype=np.float32)
+    offset_array = np.ascontiguousarray(np.array(offset_list).astype(np.int32))
+    class_dim = class_pred.shape[0]
+    offset_dim = adj_pred.shape[0]
+    img_height, img_width = adj_pred.shape[1], adj_pred.shape[2]
+    mask_pred = np.zeros((img_height, img_width)).astype(np.int32)
+    object_class_pred = np.zeros((1, img_height * img_width)).astype(np.int32)
+    lib = load_library()
+    lib.c_run_segmentation(class_pred.ctypes.data_as(_f32p), class_dim,
+                           adj_pred.ctypes.data_as(_f32p), offset_dim, img_width, img_height,
+                           int(num_classes), offset_array.ctypes.data_as(_i32p),
+                           mask_pred.ctypes.data_as(_i32p), object_class_pred.ctypes.data_as(_i32p),
+                           float(same_different_bias), float(object_merge_factor),
+                           float(merge_logprob_bias))
+    status = lib.mn_last_status()
+    if status != 0:
+        raise MergeNetError(status)      # the reference would exit(1) or crash
+    return mask_pred, _class_list(object_class_pred[0])
+
+
+class HostContext:
+    """Owns an mn_context for host-pointer calls (numpy in, numpy out)."""
+
+    def __init__(self, H: int, W: int, C: int, O: int, device: int = 0):
+        self.lib = load_library()
+        self.handle = self.lib.mn_create(device, H, W, C, O)
+        if not self.handle:
+            raise MergeNetError(self.lib.mn_last_status())
+        self.shape = (H, W, C, O)
+
+    def close(self):
+        if self.handle:
+            self.lib.mn_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def segment(self, class_probs: np.ndarray, same_probs: np.ndarray, offsets,
+                opts: Optional[MnOptions] = None, want_partition: bool = True):
+        cp = np.ascontiguousarray(class_probs, dtype=np.float32)
+        sp = np.ascontiguousarray(same_probs, dtype=np.float32)
+        C, H, W = cp.shape
+        O = sp.shape[0]
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32).reshape(-1, 2))
+        if off.shape[0] != O or sp.shape[1:] != (H, W):
+            raise AssertionError("shape mismatch between class, sameness maps and offsets")
+        opts = opts if opts is not None else default_options()
+        mask = np.zeros((H, W), np.int32)
+        table = np.zeros(H * W, np.int32)
+        part = np.zeros((H, W), np.int32) if want_partition else None
+        stats = MnStats()
+        rc = self.lib.mn_segment_host(self.handle, cp.ctypes.data_as(_f32p), C,
+                                      sp.ctypes.data_as(_f32p), O, W, H, C,
+                                      off.ctypes.data_as(_i32p), mask.ctypes.data_as(_i32p),
+                                      table.ctypes.data_as(_i32p),
+                                      part.ctypes.data_as(_i32p) if part is not None else None,
+                                      ctypes.byref(opts), ctypes.byref(stats))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return mask, _class_list(table), part, stats.as_dict()
+
+
+class ObjectSegmenter:
+    """``utils/segmenter.py:225-483`` look-alike running on the GPU (Python-variant semantics).
+
+    ``ObjectSegmenter(class_probs, sameness_probs, num_classes, offsets, opts).run_segmentation()``
+    returns ``(mask int64[H, W], object_class list)`` after ``prune(200)``.  Shape mismatches
+    raise ``AssertionError`` as the reference's asserts do (segmenter.py:245-250); a prune with
+    no class-0 object raises ``NameError`` as the reference does (segmenter.py:356,365).
+    """
+
+    def __init__(self, nnet_class_probs, nnet_sameness_probs, num_classes, offsets, opts=None):
+        self.opts = opts if opts is not None else self.default_options()
+        epsilon = np.finfo(np.float32).eps
+        self.class_probs = np.asarray(nnet_class_probs).clip(epsilon, 1.0 - epsilon)
+        self.sameness_probs = np.asarray(nnet_sameness_probs).clip(epsilon, 1.0 - epsilon)
+        self.num_classes = num_classes
+        self.offsets = offsets
+        class_dim, self.img_height, self.img_width = self.class_probs.shape
+        offset_dim, img_height, img_width = self.sameness_probs.shape
+        assert class_dim == self.num_classes
+        assert offset_dim == len(self.offsets)
+        assert self.img_height == img_height
+        assert self.img_width == img_width
+        self.stats = None
+
+    def default_options(self):
+        return SegmenterOptions(same_different_bias=0.0, object_merge_factor=1.0,
+                                merge_logprob_bias=0.0)
+
+    def run_segmentation(self, prune_threshold: float = 200.0, mode: int = MN_MODE_AUTO):
+        ctx = HostContext(self.img_height, self.img_width, self.num_classes, len(self.offsets))
+        try:
+            o = default_options(same_different_bias=float(self.opts.same_different_bias),
+                                object_merge_factor=float(self.opts.object_merge_factor),
+                                merge_logprob_bias=float(self.opts.merge_logprob_bias),
+                                variant=MN_VARIANT_PYSEGMENTER, mode=mode,
+                                prune_threshold=float(prune_threshold))
+            try:
+                mask, classes, _, self.stats = ctx.segment(self.class_probs, self.sameness_probs,
+                                                           self.offsets, o, want_partition=False)
+            except MergeNetError as e:
+                if e.status == MN_ERR_NO_BACKGROUND:
+                    raise NameError("name 'background_obj' is not defined") from None
+                raise
+        finally:
+            ctx.close()
+        return mask.astype(np.int64), classes
+
+
+class Merger:
+    """Device-resident merger for PyTorch-ROCm callers: tensors in, tensors out, no host copies.
+
+    ``class_probs`` [C,H,W] and ``same_probs`` [O,H,W] are float32 CUDA(HIP) tensors, e.g. the
+    sigmoid outputs of the network (``utils/inference_utils.py:44,96``); ``clip_inputs=1`` fuses
+    the binding's clip (c_segment.pyx:53-55) into the loads.
+    """
+
+    def __init__(self, H: int, W: int, C: int, O: int, device: Optional[int] = None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("mergenet_amd.Merger needs a HIP device; there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.lib = load_library()
+        self.handle = self.lib.mn_create(self.device, H, W, C, O)
+        if not self.handle:
+            raise MergeNetError(self.lib.mn_last_status())
+        self.H, self.W, self.C, self.O = H, W, C, O
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mn_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mn_workspace_bytes(self.handle))
+
+    def _check(self, class_probs, same_probs, offsets):
+        torch = self.torch
+        for t in (class_probs, same_probs):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 3):
+                raise ValueError("expected contiguous float32 [K,H,W] tensors on the GPU")
+            if t.device.index != self.device:
+                raise ValueError("tensor lives on another device than the Merger")
+        C, H, W = class_probs.shape
+        O = same_probs.shape[0]
+        if same_probs.shape[1:] != (H, W) or len(offsets) != O:
+            raise AssertionError("shape mismatch between class, sameness maps and offsets")
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32).reshape(-1, 2))
+        return C, H, W, O, off
+
+    def segment(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None,
+                want_partition: bool = False):
+        """Returns (mask int32[H,W] tensor, object_class int32[H*W] tensor, partition|None, stats)."""
+        torch = self.torch
+        C, H, W, O, off = self._check(class_probs, same_probs, offsets)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs.device
+        mask = torch.empty((H, W), dtype=torch.int32, device=dev)
+        table = torch.empty((H * W,), dtype=torch.int32, device=dev)
+        part = torch.empty((H, W), dtype=torch.int32, device=dev) if want_partition else None
+        stats = MnStats()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_segment_device(self.handle, class_probs.data_ptr(), C,
+                                        same_probs.data_ptr(), O, W, H, C,
+                                        off.ctypes.data_as(_i32p), mask.data_ptr(),
+                                        table.data_ptr(),
+                                        part.data_ptr() if part is not None else None,
+                                        ctypes.byref(opts), ctypes.c_void_p(stream),
+                                        ctypes.byref(stats))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return mask, table, part, stats.as_dict()
+
+    def score(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None,
+              want_arrays: bool = False):
+        """Phase A only.  Returns (ms_class_pass, ms_edge_pass[, cls uint8[H,W], best int64[H,W]])."""
+        torch = self.torch
+        C, H, W, O, off = self._check(class_probs, same_probs, offsets)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs.device
+        cls = torch.empty((H, W), dtype=torch.uint8, device=dev) if want_arrays else None
+        best = torch.empty((H, W), dtype=torch.int64, device=dev) if want_arrays else None
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_score_device(self.handle, class_probs.data_ptr(), C, same_probs.data_ptr(),
+                                      O, W, H, C, off.ctypes.data_as(_i32p), ctypes.byref(opts),
+                                      ctypes.c_void_p(stream),
+                                      cls.data_ptr() if cls is not None else None,
+                                      best.data_ptr() if best is not None else None,
+                                      ctypes.byref(a), ctypes.byref(b))
+        if rc != 0:
+            raise MergeNetError(rc)
+        if want_arrays:
+            return a.value, b.value, cls, best
+        return a.value, b.value
