@@ -79,7 +79,9 @@ typedef struct mn_stats {
   int num_objects;             /* surviving objects including class-0 ones */
   int rounds;                  /* parallel rounds executed */
   int finisher_steps;          /* sequential steps (pops) executed by the finisher */
-  int reserved_i;
+  int cert_edge_violations;    /* pixel edges whose log-odds sign contradicts the partition   */
+  int cert_class_violations;   /* pixels whose own arg-max class differs from their object's  */
+  int cert_record_violations;  /* records between final objects that are still mergeable      */
   long long initial_records;   /* in-bounds (pixel, offset) pairs */
   long long merges;            /* objects absorbed */
   double total_logprob;        /* A.4: sum lp[cls] + omf*(sum log p | log(1-p)); NaN if not asked */

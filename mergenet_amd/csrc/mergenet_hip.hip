@@ -244,6 +244,21 @@ static ObjState obj_state(mn_context* c) {
   return S;
 }
 
+// edge pass dispatch: fast form for the common offset counts, generic form otherwise
+template <bool FIRST>
+static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, u64* out) {
+  ObjState S = obj_state(c);
+  const dim3 g(grid_for(P.N, 256)), b(256);
+  const unsigned char* cls0 = c->ocls;       // unchanged until mn_pix_apply
+  const unsigned char* matched = c->matched;
+  if (P.omf > 0.0f && P.O == 10)
+    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST>), g, b, 0, st, P, cls0, matched, out);
+  else if (P.omf > 0.0f && P.O == 16)
+    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST>), g, b, 0, st, P, cls0, matched, out);
+  else
+    hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, S, matched, out);
+}
+
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
 static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge) {
   const int N = P.N;
@@ -259,8 +274,7 @@ static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool e
   }
   MN_HIP(hipEventRecord(c->ev[1], st));
   if (edge) {
-    hipLaunchKernelGGL(mn_edge_pass<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
-                       (const unsigned char*)c->matched, c->ball);
+    launch_edge_pass<true>(c, P, st, c->ball);
   }
   MN_HIP(hipEventRecord(c->ev[2], st));
   // the per-pixel arg-max is kept apart: ocls is overwritten as objects merge
@@ -339,8 +353,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
                        (const u64*)c->ball, c->matched, c->mate);
     for (int s = 1; s < subrounds; s++) {
-      hipLaunchKernelGGL(mn_edge_pass<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
-                         (const unsigned char*)c->matched, c->bsub);
+      launch_edge_pass<false>(c, P, st, c->bsub);
       hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
                          (const u64*)c->bsub, c->matched, c->mate);
     }
@@ -443,7 +456,10 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     const bool cert_opts = opts->object_merge_factor > 0.0f &&
                            (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                                                  : opts->merge_logprob_bias == 0.0f);
-    stats->certified = (c->h_scalars[0] == 0 && cert_opts) ? 1 : 0;
+    stats->cert_edge_violations = c->h_scalars[0];
+    stats->cert_class_violations = c->h_scalars[3];
+    stats->cert_record_violations = c->h_scalars[4];
+    stats->certified = (c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
     stats->num_instances = c->h_scalars[1];
     stats->num_objects = c->h_scalars[2];
     stats->rounds = rounds;
@@ -452,12 +468,12 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     stats->merges = merges;
     stats->total_logprob = c->h_lp[0];
     float ms = 0;
-    hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
-    hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
     stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
-    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
-    hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
-    hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
   }
   g_last_status = rc;
   return rc;
@@ -485,9 +501,9 @@ extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int cla
     MN_HIP(hipMemcpyAsync(d_best_out, c->ball, (size_t)P.N * sizeof(u64), hipMemcpyDeviceToDevice, st));
   MN_HIP(hipStreamSynchronize(st));
   float ms = 0;
-  hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
   if (ms_class_pass) *ms_class_pass = ms;
-  hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
   if (ms_edge_pass) *ms_edge_pass = ms;
   g_last_status = MN_OK;
   return MN_OK;

@@ -158,13 +158,13 @@ __global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
   __shared__ double sh[3][4];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double t_cls = 0.0, t_same = 0.0, t_diff = 0.0;
-  int bad = 0;
+  int bad = 0, bad_cls = 0;
   if (p < P.N) {
     const int r = p / P.W, c = p - r * P.W;
     const int ro = root[p];
     const int oc = S.ocls[ro];
     t_cls = (double)logf(mn_ld_class(P, oc, p));
-    if (cls0[p] != oc) bad++;
+    if (cls0[p] != oc) bad_cls++;
     for (int k = 0; k < P.O; k++) {
       const int rr = r + P.di[k], cc = c + P.dj[k];
       if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
@@ -181,11 +181,13 @@ __global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
     t_same += __shfl_xor(t_same, off);
     t_diff += __shfl_xor(t_diff, off);
     bad += __shfl_xor(bad, off);
+    bad_cls += __shfl_xor(bad_cls, off);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     sh[0][wave] = t_cls; sh[1][wave] = t_same; sh[2][wave] = t_diff;
     if (bad) atomicAdd(violations, bad);
+    if (bad_cls) atomicAdd(violations + 3, bad_cls);
   }
   __syncthreads();
   if (threadIdx.x < 3)
@@ -225,5 +227,5 @@ __global__ __launch_bounds__(256) void mn_verify_records(ImgParams P, ObjState S
   const float oml = mn_fixed_to_float(L.S[i]);
   const float f = mn_score(P, S, mn_key_u(key), mn_key_v(key), oml, &mc, &pos);
   const float margin = 1e-6f + 1e-5f * fabsf(P.bias);
-  if (!(f < -margin)) atomicAdd(violations, 1);
+  if (!(f < -margin)) atomicAdd(violations + 4, 1);
 }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void mn_class_pass(ImgParams P, unsigned char*
 // sub-round 0).  FIRST = false is a later matching sub-round: only edges between two still
 // unmatched pixels with positive likelihood gain compete.
 template <bool FIRST>
-__global__ __launch_bounds__(256) void mn_edge_pass(ImgParams P, ObjState S,
+__global__ __launch_bounds__(256) void mn_edge_pass_generic(ImgParams P, ObjState S,
                                                     const unsigned char* __restrict__ matched,
                                                     u64* __restrict__ best_out) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,6 +88,103 @@ __global__ __launch_bounds__(256) void mn_edge_pass(ImgParams P, ObjState S,
       if (!(prio >= 0.0f)) continue;
       if (!FIRST && !pos) continue;
       const u64 key = mn_pack(prio, q);
+      best = key > best ? key : best;
+    }
+  }
+  best_out[p] = best;
+}
+
+
+// ---- edge pass, fast form -----------------------------------------------------------------------
+// Same result as the generic form under object_merge_factor > 0, with far less arithmetic: for
+// two pixels of the SAME arg-max class the class delta is 0 and the priority is a monotone
+// function of the sameness value, so those edges are ranked by the raw value (ties: lower
+// partner id) and only the winner's log-odds are evaluated.  Edges between pixels of different
+// classes (object boundaries; rare) take the full scoring path.  All 2*O sameness loads and
+// 2*O class loads of a pixel are issued before any of them is used (OT is a compile-time offset
+// count so the staging arrays live in registers).
+__device__ __forceinline__ float mn_pixel_pair_prio(const ImgParams& P, int lo, int hi, int clo,
+                                                    int chi, float v, bool* gain_pos) {
+  // both objects are single pixels: lp = logf(class plane), n1 = n2 = 1
+  const float x = mn_same_value(P, v);
+  const float oml = mn_fixed_to_float(mn_edge_fixed(x));
+  float cdl = 0.0f;
+  if (clo != chi) {
+    float best = 0.0f, a0 = 0.0f, b0 = 0.0f;
+    for (int c = 0; c < P.C; c++) {
+      const float a = logf(mn_ld_class(P, c, lo));
+      const float b = logf(mn_ld_class(P, c, hi));
+      const float j = a + b;
+      if (c == 0 || j > best) best = j;
+      if (c == clo) a0 = a;
+      if (c == chi) b0 = b;
+    }
+    cdl = (best - a0) - b0;
+  }
+  const float num = oml * P.omf + cdl;
+  *gain_pos = num > 0.0f;
+  if (P.variant == MN_VARIANT_CSEGMENT) return num / 2.0f + P.bias;
+  return (num + P.bias) / 1.0f;
+}
+
+template <int OT, bool FIRST>
+__global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
+                                                         const unsigned char* __restrict__ cls0,
+                                                         const unsigned char* __restrict__ matched,
+                                                         u64* __restrict__ best_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  if (!FIRST && matched[p]) { best_out[p] = 0; return; }
+  const int r = p / P.W, c = p - r * P.W;
+  const int cp = cls0[p];
+  float val[2 * OT];
+  int nb[2 * OT];
+  int nbc[2 * OT];
+#pragma unroll
+  for (int k = 0; k < OT; k++) {
+    const int di = P.di[k], dj = P.dj[k];
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      const int rr = dir ? r - di : r + di;
+      const int cc = dir ? c - dj : c + dj;
+      const bool ok = rr >= 0 && rr < P.H && cc >= 0 && cc < P.W;
+      const int q = ok ? rr * P.W + cc : p;
+      const int src = dir ? q : p;
+      float v = P.same[(size_t)k * P.N + src];
+      int cq = cls0[q];
+      bool live = ok;
+      if (!FIRST) live = live && !matched[q];
+      nb[2 * k + dir] = live ? q : -1;
+      val[2 * k + dir] = v;
+      nbc[2 * k + dir] = cq;
+    }
+  }
+  float bestv = -1.0f;
+  int bestq = 0x7FFFFFFF;
+  u64 best = 0;
+#pragma unroll
+  for (int e = 0; e < 2 * OT; e++) {
+    const int q = nb[e];
+    if (q < 0) continue;
+    if (nbc[e] == cp) {
+      const float v = val[e];
+      if (v > bestv || (v == bestv && q < bestq)) { bestv = v; bestq = q; }
+    } else {
+      bool pos;
+      const int lo = min(p, q), hi = max(p, q);
+      const float prio = mn_pixel_pair_prio(P, lo, hi, lo == p ? cp : nbc[e], lo == p ? nbc[e] : cp,
+                                            val[e], &pos);
+      if (prio >= 0.0f && (FIRST || pos)) {
+        const u64 key = mn_pack(prio, q);
+        best = key > best ? key : best;
+      }
+    }
+  }
+  if (bestq != 0x7FFFFFFF) {
+    bool pos;
+    const float prio = mn_pixel_pair_prio(P, min(p, bestq), max(p, bestq), cp, cp, bestv, &pos);
+    if (prio >= 0.0f && (FIRST || pos)) {
+      const u64 key = mn_pack(prio, bestq);
       best = key > best ? key : best;
     }
   }

@@ -48,14 +48,16 @@ class MnStats(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int), ("mode_used", ctypes.c_int), ("certified", ctypes.c_int),
                 ("num_instances", ctypes.c_int), ("num_objects", ctypes.c_int),
                 ("rounds", ctypes.c_int), ("finisher_steps", ctypes.c_int),
-                ("reserved_i", ctypes.c_int), ("initial_records", ctypes.c_longlong),
+                ("cert_edge_violations", ctypes.c_int),
+                ("cert_class_violations", ctypes.c_int), ("cert_record_violations", ctypes.c_int),
+                ("initial_records", ctypes.c_longlong),
                 ("merges", ctypes.c_longlong), ("total_logprob", ctypes.c_double),
                 ("ms_score", ctypes.c_float), ("ms_class_pass", ctypes.c_float),
                 ("ms_edge_pass", ctypes.c_float), ("ms_merge", ctypes.c_float),
                 ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -75,6 +77,13 @@ def load_library() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build() / make -C "
                            "mergenet_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  If our library
+    # were loaded first it would pull /opt/rocm's copy and torch would later see no device (or
+    # vice versa), so when torch is installed its runtime is loaded first and we bind to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.mn_default_options.argtypes = [ctypes.POINTER(MnOptions)]
     lib.mn_default_options.restype = None

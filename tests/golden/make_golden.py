@@ -33,6 +33,7 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+HUGE = bool(int(os.environ.get("MN_GOLDEN_HUGE", "0")))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
@@ -117,6 +118,9 @@ def cseg_specs(big: bool):
                       seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))
     if big:
         specs.append(dict(name="cseg_synth_256x512", kind="synth", H=256, W=512, C=9,
+                          offsets=[40, 10], seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))
+    if HUGE:  # BASELINE.json configs[1]: 1024x2048 (the reference needs ~7 min and 6.5 GB)
+        specs.append(dict(name="cseg_synth_1024x2048_cfg2", kind="synth", H=1024, W=2048, C=9,
                           offsets=[40, 10], seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))
     return specs
 
