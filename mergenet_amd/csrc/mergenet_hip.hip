@@ -224,6 +224,13 @@ static void fill_params(ImgParams* P, const float* d_class, const float* d_same,
   P->variant = o->variant; P->clip = o->clip_inputs ? 1 : 0;
   P->cls = d_class; P->same = d_same;
   for (int k = 0; k < offset_dim; k++) { P->di[k] = offs[2 * k]; P->dj[k] = offs[2 * k + 1]; }
+  // pixel-level upper bound: priority <= (log-odds * omf) / den + bias with den = 2 (csegment) or
+  // (log-odds * omf + bias) / 1 (pysegmenter); solve for the sameness value, keep a safety margin
+  P->vmin_first = 0.0f;
+  if (P->omf > 0.0f) {
+    const double need = (o->variant == MN_VARIANT_CSEGMENT ? -2.0 : -1.0) * (double)P->bias / (double)P->omf;
+    P->vmin_first = (float)(1.0 / (1.0 + exp(-need)) - 1e-3);
+  }
 }
 
 static long long count_records(int W, int H, int offset_dim, const int* offs) {
@@ -247,16 +254,15 @@ static ObjState obj_state(mn_context* c) {
 // edge pass dispatch: fast form for the common offset counts, generic form otherwise
 template <bool FIRST>
 static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, u64* out) {
-  ObjState S = obj_state(c);
   const dim3 g(grid_for(P.N, 256)), b(256);
   const unsigned char* cls0 = c->ocls;       // unchanged until mn_pix_apply
   const unsigned char* matched = c->matched;
-  if (P.omf > 0.0f && P.O == 10)
+  if (P.omf > 0.0f && P.sdb == 0.0f && P.O == 10)
     hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST>), g, b, 0, st, P, cls0, matched, out);
-  else if (P.omf > 0.0f && P.O == 16)
+  else if (P.omf > 0.0f && P.sdb == 0.0f && P.O == 16)
     hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST>), g, b, 0, st, P, cls0, matched, out);
   else
-    hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, S, matched, out);
+    hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, obj_state(c), matched, out);
 }
 
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
@@ -329,7 +335,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
   const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 8192;
-  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 8;
+  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 16;
   int mode = opts->mode;
   if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS)
     mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_ROUNDS;

@@ -21,6 +21,7 @@ struct ImgParams {
   int H, W, N, C, O;
   float sdb, omf, bias;
   int variant, clip;
+  float vmin_first;    // pixel-level edges with a raw sameness value below this cannot reach priority >= 0
   const float* cls;    // [C][N] class probabilities (borrowed)
   const float* same;   // [O][N] sameness probabilities (borrowed)
   int di[MN_MAX_OFFSETS];

@@ -159,9 +159,10 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
       nbc[2 * k + dir] = cq;
     }
   }
+  // pass 1: edges to pixels of the same class, ranked by the raw value
   float bestv = -1.0f;
   int bestq = 0x7FFFFFFF;
-  u64 best = 0;
+  bool any_diff = false;
 #pragma unroll
   for (int e = 0; e < 2 * OT; e++) {
     const int q = nb[e];
@@ -170,6 +171,19 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
       const float v = val[e];
       if (v > bestv || (v == bestv && q < bestq)) { bestv = v; bestq = q; }
     } else {
+      any_diff = true;
+    }
+  }
+  // pass 2: edges across a class boundary.  Their class delta is <= 0, so such an edge can only
+  // win if its raw value is at least the best same-class value, and can only reach priority >= 0
+  // (or positive gain in later sub-rounds) above a value threshold: nearly all are skipped.
+  u64 best = 0;
+  if (any_diff) {
+    const float vmin = fmaxf(bestv, FIRST ? P.vmin_first : fmaxf(P.vmin_first, 0.499f));
+#pragma unroll 1
+    for (int e = 0; e < 2 * OT; e++) {
+      const int q = nb[e];
+      if (q < 0 || nbc[e] == cp || !(val[e] >= vmin)) continue;
       bool pos;
       const int lo = min(p, q), hi = max(p, q);
       const float prio = mn_pixel_pair_prio(P, lo, hi, lo == p ? cp : nbc[e], lo == p ? nbc[e] : cp,

@@ -25,7 +25,7 @@ def _run(g, mode=seg.MN_MODE_AUTO, **kw):
         ctx.close()
 
 
-@pytest.mark.parametrize("name", [n for n in CSEG if "256x512" not in n])
+@pytest.mark.parametrize("name", [n for n in CSEG if "256x512" not in n and "1024x2048" not in n])
 def test_golden_csegment(oracle, name):
     """Instance ids equal the REFERENCE's (its compiled segment.cc) up to label permutation."""
     g = gu.load(name)
@@ -63,6 +63,20 @@ def test_rounds_and_exact_agree_with_oracle_partition_and_loglik(oracle, name):
         # accumulation of float32 terms on both sides)
         assert abs(stats["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
         assert stats["merges"] == ref.stats["n_merges"]
+
+
+def test_golden_csegment_1024x2048_full_size(oracle):
+    """BASELINE.json configs[1]: the 1024x2048 result equals the REFERENCE's own result (its
+    segment.cc needed 536 s and 6.5 GB for this image) up to label permutation."""
+    g = gu.load("cseg_synth_1024x2048_cfg2")
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS)
+    assert stats["initial_records"] == 20745558
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+    # size-independent properties of the output: every pixel labelled, labels dense 0..K,
+    # label-0 pixels are exactly the class-0 objects, merges = pixels - objects
+    assert mask.min() == 0 and mask.max() == len(classes)
+    assert stats["merges"] == 1024 * 2048 - stats["num_objects"]
+    assert len(np.unique(part)) == stats["num_objects"]
 
 
 def test_determinism_same_input_twice():
