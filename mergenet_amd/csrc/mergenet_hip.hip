@@ -268,7 +268,6 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
 static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge) {
   const int N = P.N;
-  ObjState S = obj_state(c);
   MN_HIP(hipMemsetAsync(c->lpvalid, 0, N, st));
   MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
   hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
@@ -308,7 +307,8 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   else
     hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, 256)), dim3(256), 0, st, S, src, Rsrc, T);
   MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
-  hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, 256)), dim3(256), 0, st, P, S, T, L, c->cnt);
+  hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S, T, L,
+                     c->cnt);
   MN_HIP(hipGetLastError());
   if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
   *Rout = c->h_cnt->n_records;
@@ -371,35 +371,32 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
-    merges += c->h_cnt->n_merged;
   }
   if (mode == MN_MODE_ROUNDS) {
     while (R > finish_limit && rounds < 5000) {
       MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)N * sizeof(u64), st));
       MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
-      MN_HIP(hipMemsetAsync(c->sel, 0, R, st));
-      MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records..n_selected
-      const dim3 g(grid_for(R, 256)), b(256);
+      MN_HIP(hipMemsetAsync(c->mate, 0xFF, (size_t)N * sizeof(int), st));
+      MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records, any_selected, ...
+      const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
       hipLaunchKernelGGL(mn_rec_score, g, b, 0, st, P, S, cur, R, c->fresh, c->aux, c->ball, c->cnt);
-      hipLaunchKernelGGL(mn_rec_match, g, b, 0, st, cur, R, (const u64*)c->ball,
-                         (const unsigned char*)c->aux, 0, c->matched, c->sel);
+      hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball, c->matched,
+                         c->mate);
       for (int s = 1; s < subrounds; s++) {
         MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));
-        hipLaunchKernelGGL(mn_rec_propose, g, b, 0, st, cur, R, (const unsigned char*)c->aux,
+        hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
                            (const unsigned char*)c->matched, c->bsub);
-        hipLaunchKernelGGL(mn_rec_match, g, b, 0, st, cur, R, (const u64*)c->bsub,
-                           (const unsigned char*)c->aux, 1, c->matched, c->sel);
+        hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, (const u64*)c->bsub, c->matched, c->mate);
       }
       hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
-                         (const unsigned char*)c->aux, (const unsigned char*)c->sel, c->cnt);
+                         (const unsigned char*)c->aux, (const int*)c->mate, c->cnt);
       size_t cap = next_pow2((size_t)R * 2 + 1024);
       if (cap > c->cap) cap = c->cap;
       int Rn = 0;
       rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn);
       if (rc != MN_OK) return rc;
       rounds++;
-      merges += c->h_cnt->n_merged;
-      const int selected = c->h_cnt->n_selected;
+      const int selected = c->h_cnt->any_selected;
       RecList t = cur; cur = nxt; nxt = t;
       R = Rn;
       if (selected == 0) break;     // nothing visible any more: the queue is empty
@@ -408,7 +405,6 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
   {
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
-    MN_HIP(hipMemsetAsync(&c->cnt->n_merged, 0, sizeof(int), st));
     hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
                        c->touched_list, c->cnt, max_steps);
   }
@@ -454,7 +450,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_lp, c->lp_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
-  merges += c->h_cnt->n_merged;
+  merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
   rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
   if (stats) {
     stats->status = rc;

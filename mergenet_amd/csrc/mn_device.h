@@ -118,14 +118,18 @@ __device__ __forceinline__ float mn_score(const ImgParams& P, const ObjState& S,
 }
 
 // (priority, partner) packed so that an unsigned max picks the highest priority and, among
-// equal priorities, the LOWEST partner id.  Only priorities >= 0 are packed.
-__device__ __forceinline__ u64 mn_pack(float prio, int partner) {
+// equal priorities, the LOWEST partner id.  Only priorities >= 0 are packed.  Object ids are
+// below 2^28, which leaves bit 31 of the low word for a flag ("likelihood gain > 0") that both
+// endpoints of a record compute identically.
+__device__ __forceinline__ u64 mn_pack(float prio, int partner, bool gain_pos = false) {
   const unsigned bits = (prio == 0.0f) ? 0u : __float_as_uint(prio);
-  return ((u64)bits << 32) | (u64)(0xFFFFFFFFu - (unsigned)partner);
+  return ((u64)bits << 32) | (gain_pos ? 0x80000000ull : 0ull) |
+         (u64)(0x7FFFFFFFu - (unsigned)partner);
 }
 __device__ __forceinline__ int mn_pack_partner(u64 k) {
-  return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+  return (int)(0x7FFFFFFFu - (unsigned)(k & 0x7FFFFFFFull));
 }
+__device__ __forceinline__ bool mn_pack_gain_pos(u64 k) { return (k & 0x80000000ull) != 0; }
 
 __device__ __forceinline__ u64 mn_key(int a, int b) {
   const unsigned lo = (unsigned)min(a, b), hi = (unsigned)max(a, b);

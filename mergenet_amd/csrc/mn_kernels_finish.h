@@ -172,6 +172,6 @@ __global__ __launch_bounds__(MN_FIN_THREADS) void mn_finisher(ImgParams P, ObjSt
   if (tid == 0) {
     cnt->finisher_steps = (int)(steps > 0x7FFFFFFF ? 0x7FFFFFFF : steps);
     cnt->finisher_merges = merges;
-    atomicAdd(&cnt->n_merged, merges);
+    cnt->n_merged = merges;
   }
 }

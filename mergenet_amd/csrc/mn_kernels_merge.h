@@ -34,10 +34,11 @@ struct HashTab {
 };
 
 struct Counters {
-  int n_records;     // appended by the compaction kernels
-  int n_visible;     // records with stored priority >= 0
-  int n_merged;      // objects absorbed this round
-  int n_selected;    // records selected (merged or refreshed)
+  int n_records;     // appended by the compaction kernel (one atomic per 1024 slots)
+  int any_selected;  // set when a round selected at least one record (plain store, no atomic:
+                     // a single hot counter word caps out near 88 atomics/us on this chip)
+  int n_merged;      // merges done by the sequential finisher
+  int pad0;
   int finisher_steps;
   int finisher_merges;
   int error;
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(256) void mn_pix_apply(ImgParams P, ObjState S,
   S.ocls[p] = (unsigned char)mc;
   S.osize[p] = 2;
   S.parent[q] = p;
-  atomicAdd(&cnt->n_merged, 1);
 }
 
 // ---- open-addressing table of records ---------------------------------------------------------
@@ -130,31 +130,56 @@ __global__ __launch_bounds__(256) void mn_build_from_pixels(ImgParams P, ObjStat
 }
 
 // Table -> compact list; touched records get a fresh priority (they were re-keyed or folded).
+// A block owns 1024 consecutive slots and reserves its output range with ONE atomic.
+#define MN_COMPACT_SLOTS 1024
 __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashTab T, RecList L,
                                                   Counters* __restrict__ cnt) {
-  const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot > T.mask) return;
-  const u64 key = T.key[slot];
-  if (key == MN_EMPTY) return;
-  const i64 s = T.S[slot];
-  float st;
-  if (T.touched[slot]) {
-    int mc;
-    bool pos;
-    st = mn_score(P, S, mn_key_u(key), mn_key_v(key), mn_fixed_to_float(s), &mc, &pos);
-  } else {
-    st = T.st[slot];
+  __shared__ int sh_w[4][4];
+  __shared__ int sh_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned base = blockIdx.x * MN_COMPACT_SLOTS;
+  u64 key[4];
+  int before[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned slot = base + j * 256 + threadIdx.x;
+    key[j] = slot <= T.mask ? T.key[slot] : MN_EMPTY;
+    const u64 m = __ballot(key[j] != MN_EMPTY);
+    before[j] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sh_w[j][wave] = __popcll(m);
   }
-  const int idx = atomicAdd(&cnt->n_records, 1);
-  L.key[idx] = key;
-  L.S[idx] = s;
-  L.st[idx] = st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int j = 0; j < 4; j++)
+      for (int w = 0; w < 4; w++) { const int t = sh_w[j][w]; sh_w[j][w] = tot; tot += t; }
+    sh_base = tot ? atomicAdd(&cnt->n_records, tot) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (key[j] == MN_EMPTY) continue;
+    const unsigned slot = base + j * 256 + threadIdx.x;
+    const i64 s = T.S[slot];
+    float st;
+    if (T.touched[slot]) {
+      int mc;
+      bool pos;
+      st = mn_score(P, S, mn_key_u(key[j]), mn_key_v(key[j]), mn_fixed_to_float(s), &mc, &pos);
+    } else {
+      st = T.st[slot];
+    }
+    const int idx = sh_base + sh_w[j][wave] + before[j];
+    L.key[idx] = key[j];
+    L.S[idx] = s;
+    L.st[idx] = st;
+  }
 }
 
 // ---- rounds on the explicit record list -------------------------------------------------------
 
 // fresh priority of every record; eager refresh of stale-high records; best visible record per
-// object (ball = "best of all").
+// object (ball = "best of all", with the record's gain>0 flag in the key).
 __global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, RecList L, int R,
                                                     float* __restrict__ fresh,
                                                     unsigned char* __restrict__ aux,
@@ -172,56 +197,68 @@ __global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, Rec
   fresh[i] = f;
   aux[i] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // aux: merged class | gain>0 flag
   if (st >= 0.0f) {
-    atomicMax(&ball[u], mn_pack(st, v));
-    atomicMax(&ball[v], mn_pack(st, u));
-    atomicAdd(&cnt->n_visible, 1);
+    atomicMax(&ball[u], mn_pack(st, v, pos));
+    atomicMax(&ball[v], mn_pack(st, u, pos));
   }
 }
 
-// later sub-rounds: records between two unmatched objects with positive gain propose again
-__global__ __launch_bounds__(256) void mn_rec_propose(RecList L, int R,
-                                                      const unsigned char* __restrict__ aux,
-                                                      const unsigned char* __restrict__ matched,
-                                                      u64* __restrict__ bsub) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  const float st = L.st[i];
-  if (!(st >= 0.0f) || !(aux[i] & 0x80)) return;
-  const u64 key = L.key[i];
-  const int u = mn_key_u(key), v = mn_key_v(key);
-  if (matched[u] || matched[v]) return;
-  atomicMax(&bsub[u], mn_pack(st, v));
-  atomicMax(&bsub[v], mn_pack(st, u));
+// ---- matching on the best-record forest (object-level passes) ----------------------------------
+// ball[u] names u's best visible record.  Sub-round 0 pairs the objects that name each other.
+// Later sub-rounds work on the forest "u -> partner(ball[u])" only: an object whose own choice
+// has just been taken by somebody else ("jilted") accepts the best still-free object that chose
+// it, provided that record has positive likelihood gain.  Every merged record is therefore the
+// best record of at least one of its endpoints, and no object is in two pairs.
+__global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __restrict__ ball,
+                                                           unsigned char* __restrict__ matched,
+                                                           int* __restrict__ mate) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  const u64 b = ball[u];
+  if (b == 0) return;
+  const int t = mn_pack_partner(b);
+  const u64 bt = ball[t];
+  if (bt == 0 || mn_pack_partner(bt) != u) return;
+  matched[u] = 1;
+  mate[u] = t;
 }
 
-// a record is selected when it is the best of both its endpoints
-__global__ __launch_bounds__(256) void mn_rec_match(RecList L, int R, const u64* __restrict__ bcur,
-                                                    const unsigned char* __restrict__ aux,
-                                                    int later_subround,
-                                                    unsigned char* __restrict__ matched,
-                                                    unsigned char* __restrict__ sel) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  const float st = L.st[i];
-  if (!(st >= 0.0f)) return;
-  if (later_subround && !(aux[i] & 0x80)) return;
-  const u64 key = L.key[i];
-  const int u = mn_key_u(key), v = mn_key_v(key);
-  if (bcur[u] != mn_pack(st, v) || bcur[v] != mn_pack(st, u)) return;
-  sel[i] = 1;
-  matched[u] = 1;
-  matched[v] = 1;
+__global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restrict__ ball,
+                                                      const unsigned char* __restrict__ matched,
+                                                      u64* __restrict__ inbest) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N || matched[u]) return;
+  const u64 b = ball[u];
+  if (b == 0 || !mn_pack_gain_pos(b)) return;
+  const int t = mn_pack_partner(b);
+  if (matched[t]) return;
+  const u64 bt = ball[t];
+  if (bt == 0 || !matched[mn_pack_partner(bt)]) return;     // t still waits for its own choice
+  atomicMax(&inbest[t], (b & 0xFFFFFFFF00000000ull) | (u64)(0x7FFFFFFFu - (unsigned)u));
+}
+
+__global__ __launch_bounds__(256) void mn_obj_accept(int N, const u64* __restrict__ inbest,
+                                                     unsigned char* __restrict__ matched,
+                                                     int* __restrict__ mate) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const u64 k = inbest[t];
+  if (k == 0 || matched[t]) return;
+  const int u = mn_pack_partner(k);
+  matched[t] = 1; mate[t] = u;
+  matched[u] = 1; mate[u] = t;
 }
 
 // Selected records: refresh (stale-low) or merge (segment.cc:560-565, 602-642).
 __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, RecList L, int R,
                                                     const float* __restrict__ fresh,
                                                     const unsigned char* __restrict__ aux,
-                                                    const unsigned char* __restrict__ sel,
+                                                    const int* __restrict__ mate,
                                                     Counters* __restrict__ cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R || !sel[i]) return;
-  atomicAdd(&cnt->n_selected, 1);
+  if (i >= R) return;
+  const u64 key0 = L.key[i];
+  if (mate[mn_key_u(key0)] != mn_key_v(key0)) return;     // not the record of a matched pair
+  cnt->any_selected = 1;
   const float f = fresh[i], st = L.st[i];
   // csegment merges when the re-scored priority equals the popped one (segment.cc:561); a
   // record whose priority rose since it was stored is re-queued with the new value instead.
@@ -238,7 +275,6 @@ __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, Rec
   S.ocls[a] = (unsigned char)(aux[i] & 0x7F);
   S.osize[a] = na + nb;
   S.parent[b] = a;
-  atomicAdd(&cnt->n_merged, 1);
 }
 
 // Re-insert every record under its relabelled key; records inside one object disappear.
