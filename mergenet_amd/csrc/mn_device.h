@@ -21,6 +21,7 @@ struct ImgParams {
   int H, W, N, C, O;
   float sdb, omf, bias;
   int variant, clip;
+  int banded;          // 1: XCD-banded tile order in the neighbour-reading kernels (mn_xcd_tile)
   float vmin_first;    // pixel-level edges with a raw sameness value below this cannot reach priority >= 0
   const float* cls;    // [C][N] class probabilities (borrowed)
   const float* same;   // [O][N] sameness probabilities (borrowed)
@@ -145,4 +146,17 @@ __device__ __forceinline__ unsigned mn_hash(u64 k) {
   k *= 0xc4ceb9fe1a85ec53ull;
   k ^= k >> 33;
   return (unsigned)k;
+}
+
+// XCD-aware tile order for kernels whose neighbouring tiles re-read each other's rows (shifted
+// neighbour loads).  Workgroups are dealt round-robin over the 8 XCDs, each with a private L2:
+// with the identity mapping the rows a tile needs from its neighbours were fetched into ANOTHER
+// XCD's L2.  Here XCD j walks the contiguous band of tiles [j*chunk, (j+1)*chunk) in order, so
+// the shifted re-reads hit its own L2.  Launch 8*chunk blocks; returns -1 for padding blocks.
+// Speed only: any placement gives the same result.
+__device__ __forceinline__ int mn_xcd_tile(int ntiles, int banded) {
+  if (!banded) return (int)blockIdx.x < ntiles ? (int)blockIdx.x : -1;
+  const int chunk = (ntiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  return ((int)(blockIdx.x >> 3) < chunk && tile < ntiles) ? tile : -1;
 }

@@ -184,21 +184,45 @@ __global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, Rec
                                                     float* __restrict__ fresh,
                                                     unsigned char* __restrict__ aux,
                                                     u64* __restrict__ ball,
-                                                    Counters* __restrict__ cnt) {
+                                                    unsigned* __restrict__ gmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  const u64 key = L.key[i];
-  const int u = mn_key_u(key), v = mn_key_v(key);
-  int mc;
-  bool pos;
-  const float f = mn_score(P, S, u, v, mn_fixed_to_float(L.S[i]), &mc, &pos);
-  float st = L.st[i];
-  if (st >= 0.0f && f < st) { st = f; L.st[i] = f; }
-  fresh[i] = f;
-  aux[i] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // aux: merged class | gain>0 flag
-  if (st >= 0.0f) {
-    atomicMax(&ball[u], mn_pack(st, v, pos));
-    atomicMax(&ball[v], mn_pack(st, u, pos));
+  unsigned mybits = 0;
+  if (i < R) {
+    const u64 key = L.key[i];
+    const int u = mn_key_u(key), v = mn_key_v(key);
+    int mc;
+    bool pos;
+    const float f = mn_score(P, S, u, v, mn_fixed_to_float(L.S[i]), &mc, &pos);
+    float st = L.st[i];
+    if (st >= 0.0f && f < st) { st = f; L.st[i] = f; }
+    fresh[i] = f;
+    aux[i] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // aux: merged class | gain>0 flag
+    if (st >= 0.0f) {
+      atomicMax(&ball[u], mn_pack(st, v, pos));
+      atomicMax(&ball[v], mn_pack(st, u, pos));
+      mybits = (st == 0.0f) ? 0u : __float_as_uint(st);
+    }
+  }
+  // highest visible priority of the round (for the band threshold), spread over 64 words
+  for (int off = 32; off > 0; off >>= 1) mybits = max(mybits, (unsigned)__shfl_xor((int)mybits, off));
+  if ((threadIdx.x & 63) == 0 && mybits) atomicMax(&gmax[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], mybits);
+}
+
+// Band threshold of the round.  The reference pops records in globally descending priority; a
+// round may only merge records whose likelihood gain is within a factor `gamma` of the round's
+// best gain, so weak (bias-driven) merges of big objects wait until the strong ones are done
+// everywhere, as they do in the queue.  csegment: gain/den = priority - bias; pysegmenter carries
+// the bias inside the fraction, so the band is taken on the priority itself.
+__global__ void mn_band_threshold(const unsigned* __restrict__ gmax, float bias, int variant,
+                                  float gamma, float* __restrict__ theta) {
+  unsigned m = gmax[threadIdx.x & 63];
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if (threadIdx.x == 0) {
+    const float pmax = __uint_as_float(m);
+    float t;
+    if (variant == MN_VARIANT_CSEGMENT) t = pmax > bias ? bias + gamma * (pmax - bias) : 0.0f;
+    else t = gamma * pmax;
+    *theta = t;
   }
 }
 
@@ -208,13 +232,18 @@ __global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, Rec
 // has just been taken by somebody else ("jilted") accepts the best still-free object that chose
 // it, provided that record has positive likelihood gain.  Every merged record is therefore the
 // best record of at least one of its endpoints, and no object is in two pairs.
+__device__ __forceinline__ bool mn_in_band(u64 packed, float theta) {
+  return __uint_as_float((unsigned)(packed >> 32)) >= theta;
+}
+
 __global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __restrict__ ball,
+                                                           const float* __restrict__ theta,
                                                            unsigned char* __restrict__ matched,
                                                            int* __restrict__ mate) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   const u64 b = ball[u];
-  if (b == 0) return;
+  if (b == 0 || !mn_in_band(b, *theta)) return;
   const int t = mn_pack_partner(b);
   const u64 bt = ball[t];
   if (bt == 0 || mn_pack_partner(bt) != u) return;
@@ -223,12 +252,13 @@ __global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __r
 }
 
 __global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restrict__ ball,
+                                                      const float* __restrict__ theta,
                                                       const unsigned char* __restrict__ matched,
                                                       u64* __restrict__ inbest) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N || matched[u]) return;
   const u64 b = ball[u];
-  if (b == 0 || !mn_pack_gain_pos(b)) return;
+  if (b == 0 || !mn_pack_gain_pos(b) || !mn_in_band(b, *theta)) return;
   const int t = mn_pack_partner(b);
   if (matched[t]) return;
   const u64 bt = ball[t];
@@ -246,6 +276,20 @@ __global__ __launch_bounds__(256) void mn_obj_accept(int N, const u64* __restric
   const int u = mn_pack_partner(k);
   matched[t] = 1; mate[t] = u;
   matched[u] = 1; mate[u] = t;
+}
+
+// Hand-over to the sequential finisher: every record gets its current priority.  The parallel
+// rounds grow objects in a different order than the reference's queue, so WHICH records are
+// left stale (a survivor's untouched records, segment.cc:650-707) is an artefact of the rounds;
+// the sequential phase starts from the state "all records fresh", as the exact mode does.
+__global__ __launch_bounds__(256) void mn_rec_refresh(ImgParams P, ObjState S, RecList L, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const u64 key = L.key[i];
+  if (key == MN_EMPTY) return;
+  int mc;
+  bool pos;
+  L.st[i] = mn_score(P, S, mn_key_u(key), mn_key_v(key), mn_fixed_to_float(L.S[i]), &mc, &pos);
 }
 
 // Selected records: refresh (stale-low) or merge (segment.cc:560-565, 602-642).

@@ -132,14 +132,18 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
                                                          const unsigned char* __restrict__ cls0,
                                                          const unsigned char* __restrict__ matched,
                                                          u64* __restrict__ best_out) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = mn_xcd_tile((P.N + 255) >> 8, P.banded);
+  if (tile < 0) return;
+  const int p = tile * 256 + threadIdx.x;
   if (p >= P.N) return;
   if (!FIRST && matched[p]) { best_out[p] = 0; return; }
   const int r = p / P.W, c = p - r * P.W;
   const int cp = cls0[p];
-  float val[2 * OT];
-  int nb[2 * OT];
-  int nbc[2 * OT];
+  // pass 1 (branch-free): edges to pixels of the same class, ranked by (raw value, lower id)
+  // through one 64-bit max of (value bits << 32 | ~partner); values are in (0, 1], so their
+  // bit patterns order like the floats.
+  u64 bestkey = 0;
+  float diffmax = -1.0f;      // largest raw value on an edge across a class boundary
 #pragma unroll
   for (int k = 0; k < OT; k++) {
     const int di = P.di[k], dj = P.dj[k];
@@ -147,54 +151,52 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
     for (int dir = 0; dir < 2; dir++) {
       const int rr = dir ? r - di : r + di;
       const int cc = dir ? c - dj : c + dj;
-      const bool ok = rr >= 0 && rr < P.H && cc >= 0 && cc < P.W;
+      const bool ok = (unsigned)rr < (unsigned)P.H && (unsigned)cc < (unsigned)P.W;
       const int q = ok ? rr * P.W + cc : p;
       const int src = dir ? q : p;
       float v = P.same[(size_t)k * P.N + src];
-      int cq = cls0[q];
+      if (P.clip) v = mn_clip(v);
+      const int cq = cls0[q];
       bool live = ok;
       if (!FIRST) live = live && !matched[q];
-      nb[2 * k + dir] = live ? q : -1;
-      val[2 * k + dir] = v;
-      nbc[2 * k + dir] = cq;
+      const bool samec = live && cq == cp;
+      diffmax = (live && cq != cp) ? fmaxf(diffmax, v) : diffmax;
+      const u64 key = ((u64)__float_as_uint(v) << 32) | (u64)(0x7FFFFFFFu - (unsigned)q);
+      const u64 cand = samec ? key : 0ull;
+      bestkey = cand > bestkey ? cand : bestkey;
     }
   }
-  // pass 1: edges to pixels of the same class, ranked by the raw value
-  float bestv = -1.0f;
-  int bestq = 0x7FFFFFFF;
-  bool any_diff = false;
-#pragma unroll
-  for (int e = 0; e < 2 * OT; e++) {
-    const int q = nb[e];
-    if (q < 0) continue;
-    if (nbc[e] == cp) {
-      const float v = val[e];
-      if (v > bestv || (v == bestv && q < bestq)) { bestv = v; bestq = q; }
-    } else {
-      any_diff = true;
-    }
-  }
-  // pass 2: edges across a class boundary.  Their class delta is <= 0, so such an edge can only
-  // win if its raw value is at least the best same-class value, and can only reach priority >= 0
-  // (or positive gain in later sub-rounds) above a value threshold: nearly all are skipped.
+  const float bestv = bestkey ? __uint_as_float((unsigned)(bestkey >> 32)) : -1.0f;
+  const int bestq = mn_pack_partner(bestkey);
+  // pass 2: edges across a class boundary (rare).  Their class delta is <= 0, so such an edge can
+  // only win if its raw value is at least the best same-class value, and can only reach priority
+  // >= 0 (or positive gain in later sub-rounds) above a value threshold: nearly all are skipped.
   u64 best = 0;
-  if (any_diff) {
-    const float vmin = fmaxf(bestv, FIRST ? P.vmin_first : fmaxf(P.vmin_first, 0.499f));
+  const float vmin = fmaxf(bestv, FIRST ? P.vmin_first : fmaxf(P.vmin_first, 0.499f));
+  if (diffmax >= vmin) {
 #pragma unroll 1
     for (int e = 0; e < 2 * OT; e++) {
-      const int q = nb[e];
-      if (q < 0 || nbc[e] == cp || !(val[e] >= vmin)) continue;
+      const int k = e >> 1, dir = e & 1;
+      const int rr = dir ? r - P.di[k] : r + P.di[k];
+      const int cc = dir ? c - P.dj[k] : c + P.dj[k];
+      if (!((unsigned)rr < (unsigned)P.H && (unsigned)cc < (unsigned)P.W)) continue;
+      const int q = rr * P.W + cc;
+      if (!FIRST && matched[q]) continue;
+      const int cq = cls0[q];
+      if (cq == cp) continue;
+      float v = P.same[(size_t)k * P.N + (dir ? q : p)];
+      if (P.clip) v = mn_clip(v);
+      if (!(v >= vmin)) continue;
       bool pos;
       const int lo = min(p, q), hi = max(p, q);
-      const float prio = mn_pixel_pair_prio(P, lo, hi, lo == p ? cp : nbc[e], lo == p ? nbc[e] : cp,
-                                            val[e], &pos);
+      const float prio = mn_pixel_pair_prio(P, lo, hi, lo == p ? cp : cq, lo == p ? cq : cp, v, &pos);
       if (prio >= 0.0f && (FIRST || pos)) {
         const u64 key = mn_pack(prio, q);
         best = key > best ? key : best;
       }
     }
   }
-  if (bestq != 0x7FFFFFFF) {
+  if (bestkey) {
     bool pos;
     const float prio = mn_pixel_pair_prio(P, min(p, bestq), max(p, bestq), cp, cp, bestv, &pos);
     if (prio >= 0.0f && (FIRST || pos)) {

@@ -1,0 +1,131 @@
+// Micro-benchmark of edge-pass variants (design study; GPU box only).
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/edge_bench.hip -o /tmp/edge_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../mergenet_amd/csrc/mn_device.h"
+#include "../mergenet_amd/csrc/mn_kernels_score.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+// variant flags: 1 = skip class bytes, 2 = skip shifted loads, 4 = skip winner math, 8 = banded tiles
+template <int OT, int V>
+__global__ __launch_bounds__(256) void edge_variant(ImgParams P, const unsigned char* __restrict__ cls0,
+                                                    u64* __restrict__ best_out) {
+  int tile = blockIdx.x;
+  if (V & 8) { tile = mn_xcd_tile((P.N + 255) >> 8, 1); if (tile < 0) return; }
+  const int p = tile * 256 + threadIdx.x;
+  if (p >= P.N) return;
+  const int r = p / P.W, c = p - r * P.W;
+  const int cp = (V & 1) ? 0 : cls0[p];
+  u64 bestkey = 0;
+#pragma unroll
+  for (int k = 0; k < OT; k++) {
+    const int di = P.di[k], dj = P.dj[k];
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      const int rr = dir ? r - di : r + di;
+      const int cc = dir ? c - dj : c + dj;
+      const bool ok = (unsigned)rr < (unsigned)P.H && (unsigned)cc < (unsigned)P.W;
+      const int q = ok ? rr * P.W + cc : p;
+      const int src = (dir && !(V & 2)) ? q : p;
+      float v = P.same[(size_t)k * P.N + src];
+      const int cq = (V & 1) ? 0 : cls0[q];
+      const bool samec = ok && cq == cp;
+      const u64 key = ((u64)__float_as_uint(v) << 32) | (u64)(0x7FFFFFFFu - (unsigned)q);
+      const u64 cand = samec ? key : 0ull;
+      bestkey = cand > bestkey ? cand : bestkey;
+    }
+  }
+  u64 best = bestkey;
+  if (!(V & 4) && bestkey) {
+    bool pos;
+    const float bestv = __uint_as_float((unsigned)(bestkey >> 32));
+    const int bestq = mn_pack_partner(bestkey);
+    const float prio = mn_pixel_pair_prio(P, min(p, bestq), max(p, bestq), cp, cp, bestv, &pos);
+    best = prio >= 0.0f ? mn_pack(prio, bestq) : 0;
+  }
+  best_out[p] = best;
+}
+
+// 4 pixels per lane: float4 own loads, 4 scalar shifted loads
+template <int OT>
+__global__ __launch_bounds__(256) void edge_vec4(ImgParams P, const unsigned char* __restrict__ cls0,
+                                                 u64* __restrict__ best_out) {
+  const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= P.N) return;
+  const int r = p0 / P.W, c0 = p0 - r * P.W;      // W % 4 == 0: the 4 pixels share a row
+  const uchar4 cp4 = *reinterpret_cast<const uchar4*>(cls0 + p0);
+  const int cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+  u64 bestkey[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < OT; k++) {
+    const int di = P.di[k], dj = P.dj[k];
+    const float4 own = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
+    const float ownv[4] = {own.x, own.y, own.z, own.w};
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      const int rr = dir ? r - di : r + di;
+      const bool rok = (unsigned)rr < (unsigned)P.H;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int cc = dir ? c0 + j - dj : c0 + j + dj;
+        const bool ok = rok && (unsigned)cc < (unsigned)P.W;
+        const int q = ok ? rr * P.W + cc : p0 + j;
+        const float v = dir ? P.same[(size_t)k * P.N + q] : ownv[j];
+        const int cq = cls0[q];
+        const bool samec = ok && cq == cpv[j];
+        const u64 key = ((u64)__float_as_uint(v) << 32) | (u64)(0x7FFFFFFFu - (unsigned)q);
+        const u64 cand = samec ? key : 0ull;
+        bestkey[j] = cand > bestkey[j] ? cand : bestkey[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u64 best = 0;
+    if (bestkey[j]) {
+      bool pos;
+      const float bestv = __uint_as_float((unsigned)(bestkey[j] >> 32));
+      const int bestq = mn_pack_partner(bestkey[j]);
+      const int p = p0 + j;
+      const float prio = mn_pixel_pair_prio(P, min(p, bestq), max(p, bestq), cpv[j], cpv[j], bestv, &pos);
+      best = prio >= 0.0f ? mn_pack(prio, bestq) : 0;
+    }
+    best_out[p0 + j] = best;
+  }
+}
+
+int main() {
+  const int H = 1024, W = 2048, C = 9, O = 10, N = H * W;
+  const int offs[20] = {1,0, 0,1, -2,-1, 2,-3, 4,3, -6,5, -6,-10, 17,-6, 5,26, -40,0};
+  std::vector<float> h((size_t)O * N);
+  unsigned s = 12345;
+  for (size_t i = 0; i < h.size(); i++) { s = s * 1664525u + 1013904223u; h[i] = 0.75f + 0.24f * ((s >> 8) * (1.0f / 16777216.0f)); }
+  float *d_same, *d_cls; unsigned char* d_c0; u64* d_best;
+  CK(hipMalloc(&d_same, h.size() * 4)); CK(hipMalloc(&d_cls, (size_t)C * N * 4)); CK(hipMalloc(&d_c0, N)); CK(hipMalloc(&d_best, (size_t)N * 8));
+  CK(hipMemcpy(d_same, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_cls, 0x3f, (size_t)C * N * 4)); CK(hipMemset(d_c0, 0, N));
+  ImgParams P; memset(&P, 0, sizeof(P));
+  P.H = H; P.W = W; P.N = N; P.C = C; P.O = O; P.omf = 1.0f; P.bias = 0.03f; P.cls = d_cls; P.same = d_same; P.vmin_first = 0.48f;
+  for (int k = 0; k < O; k++) { P.di[k] = offs[2 * k]; P.dj[k] = offs[2 * k + 1]; }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](const char* name, auto launch) {
+    for (int i = 0; i < 3; i++) launch();
+    CK(hipEventRecord(e0)); for (int i = 0; i < 20; i++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("%-28s %.1f us\n", name, ms * 1000 / 20);
+  };
+  const dim3 g((N + 255) / 256), gx(8 * (((N + 255) / 256 + 7) / 8)), b(256);
+  timeit("full", [&] { hipLaunchKernelGGL((edge_variant<10, 0>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("no class bytes", [&] { hipLaunchKernelGGL((edge_variant<10, 1>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("no shifted loads", [&] { hipLaunchKernelGGL((edge_variant<10, 2>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("no winner math", [&] { hipLaunchKernelGGL((edge_variant<10, 4>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("no bytes, no shifted", [&] { hipLaunchKernelGGL((edge_variant<10, 3>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("no bytes/shifted/math", [&] { hipLaunchKernelGGL((edge_variant<10, 7>), g, b, 0, 0, P, d_c0, d_best); });
+  timeit("banded full", [&] { hipLaunchKernelGGL((edge_variant<10, 8>), gx, b, 0, 0, P, d_c0, d_best); });
+  timeit("vec4", [&] { hipLaunchKernelGGL((edge_vec4<10>), dim3((N / 4 + 255) / 256), b, 0, 0, P, d_c0, d_best); });
+  timeit("product kernel", [&] { hipLaunchKernelGGL((mn_edge_pass_fast<10, true>), gx, b, 0, 0, P, d_c0, (const unsigned char*)d_c0, d_best); });
+  return 0;
+}
