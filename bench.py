@@ -134,6 +134,13 @@ def main():
         avg_score_ms = sum(score_ms) / len(score_ms)
         algo_bytes = 4.0 * (C + len(offs)) * H * W
         achieved = algo_bytes / (avg_score_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, FETCH_SIZE x2 on gfx950): collected once per round, kept in profiles/
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_score_1024x2048.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("affinity_scoring_pass_hbm_bytes_per_launch")
         out = {
             "metric": "merged Mpixels/sec at 1024x2048",
             "value": round(world * args.steps * H * W / elapsed / 1e6, 4),
@@ -153,12 +160,15 @@ def main():
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": len(offs),
                        "exchange": "all_gather of int32 masks + class tables over RCCL" if world > 1
                                    else "none (single GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "affinity-scoring pass = mn_class_pass + mn_edge_pass<true>",
+            "roofline": {"bound": "hbm", "kernel": "affinity-scoring pass = mn_class_pass + mn_edge_pass_fast<10,true>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": algo_bytes, "avg_launch_ms": round(avg_score_ms, 5),
                          "class_pass_ms": round(sum(class_ms) / len(class_ms), 5),
-                         "edge_pass_ms": round(sum(edge_ms) / len(edge_ms), 5)},
+                         "edge_pass_ms": round(sum(edge_ms) / len(edge_ms), 5),
+                         "timing": "hipEvent pairs on the launch stream around each kernel (includes "
+                                   "the ~5 us dispatch gap per kernel; rocprofv3 kernel-only "
+                                   "durations are in profiles/r01_bench_kernel_stats.csv)"},
             "phases_ms": {"score": round(avg_score_ms, 4),
                           "merge": round(sum(merge_ms) / len(merge_ms), 4),
                           "output": round(sum(out_ms) / len(out_ms), 4)},

@@ -122,7 +122,7 @@ def cseg_specs(big: bool):
     if HUGE:  # BASELINE.json configs[1]: 1024x2048 (the reference needs ~9 min and 6.5 GB each)
         specs.append(dict(name="cseg_synth_1024x2048_cfg2", kind="synth", H=1024, W=2048, C=9,
                           offsets=[40, 10], seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))
-        for sd in (1001, 1002):      # images of ranks 1, 2 in the multi-GPU bench
+        for sd in (1001, 1002, 1003, 1004, 1005, 1006, 1007):   # images of ranks 1..7 (configs[2])
             specs.append(dict(name="cseg_synth_1024x2048_s%d" % sd, kind="synth", H=1024, W=2048,
                               C=9, offsets=[40, 10], seed=sd, noise=0.15, opts=(0.0, 1.0, 0.03)))
         for sd in (1000, 1001, 1002):  # the size the reference's own caller uses (segment.py:93)

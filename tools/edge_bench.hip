@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "../mergenet_amd/csrc/mn_device.h"
 #include "../mergenet_amd/csrc/mn_kernels_score.h"
@@ -98,7 +99,30 @@ __global__ __launch_bounds__(256) void edge_vec4(ImgParams P, const unsigned cha
   }
 }
 
-int main() {
+// calibration of the FETCH_SIZE counter: known byte counts, dword and dwordx4 loads per lane
+__global__ __launch_bounds__(256) void calib_dword(const float* __restrict__ x, size_t n, float* out) {
+  float acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += x[i];
+  if (acc == 12345.678f) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_x4(const float4* __restrict__ x, size_t n4, float* out) {
+  float acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 v = x[i]; acc += v.x + v.y + v.z + v.w; }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "calib") {
+    const size_t n = (size_t)256 << 20;   // 256 Mi floats = 1 GiB, beyond the 256 MiB Infinity Cache
+    float* d; float* o; CK(hipMalloc(&d, n * 4)); CK(hipMalloc(&o, 16)); CK(hipMemset(d, 0, n * 4));
+    for (int i = 0; i < 3; i++) {
+      hipLaunchKernelGGL(calib_dword, dim3(8192), dim3(256), 0, 0, d, n, o);
+      hipLaunchKernelGGL(calib_x4, dim3(8192), dim3(256), 0, 0, (const float4*)d, n / 4, o);
+    }
+    CK(hipDeviceSynchronize());
+    printf("calibration kernels read %zu bytes each\n", n * 4);
+    return 0;
+  }
   const int H = 1024, W = 2048, C = 9, O = 10, N = H * W;
   const int offs[20] = {1,0, 0,1, -2,-1, 2,-3, 4,3, -6,5, -6,-10, 17,-6, 5,26, -40,0};
   std::vector<float> h((size_t)O * N);
