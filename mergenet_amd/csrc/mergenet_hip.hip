@@ -400,11 +400,11 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                          P.bias, P.variant, band_gamma, c->theta);
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
                          (const float*)c->theta, c->matched, c->mate);
+      MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));   // accept cleans up after
       for (int s = 1; s < subrounds; s++) {
-        MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));
         hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
                            (const float*)c->theta, (const unsigned char*)c->matched, c->bsub);
-        hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, (const u64*)c->bsub, c->matched, c->mate);
+        hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate);
       }
       hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
                          (const unsigned char*)c->aux, (const int*)c->mate, c->cnt);

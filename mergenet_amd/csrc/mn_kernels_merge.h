@@ -198,8 +198,11 @@ __global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, Rec
     fresh[i] = f;
     aux[i] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // aux: merged class | gain>0 flag
     if (st >= 0.0f) {
-      atomicMax(&ball[u], mn_pack(st, v, pos));
-      atomicMax(&ball[v], mn_pack(st, u, pos));
+      // a plain look first: most records lose against what is already there (an object has tens
+      // of records, a running maximum changes ~ln(n) times), and a lost race only costs the atomic
+      const u64 ku = mn_pack(st, v, pos), kv = mn_pack(st, u, pos);
+      if (ku > ball[u]) atomicMax(&ball[u], ku);
+      if (kv > ball[v]) atomicMax(&ball[v], kv);
       mybits = (st == 0.0f) ? 0u : __float_as_uint(st);
     }
   }
@@ -266,13 +269,15 @@ __global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restri
   atomicMax(&inbest[t], (b & 0xFFFFFFFF00000000ull) | (u64)(0x7FFFFFFFu - (unsigned)u));
 }
 
-__global__ __launch_bounds__(256) void mn_obj_accept(int N, const u64* __restrict__ inbest,
+__global__ __launch_bounds__(256) void mn_obj_accept(int N, u64* __restrict__ inbest,
                                                      unsigned char* __restrict__ matched,
                                                      int* __restrict__ mate) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
   const u64 k = inbest[t];
-  if (k == 0 || matched[t]) return;
+  if (k == 0) return;
+  inbest[t] = 0;                       // self-cleaning: no memset between sub-rounds
+  if (matched[t]) return;
   const int u = mn_pack_partner(k);
   matched[t] = 1; mate[t] = u;
   matched[u] = 1; mate[u] = t;
