@@ -136,3 +136,55 @@ def test_golden_pysegmenter(oracle, name):
     mask, classes = s.run_segmentation(prune_threshold=thr, mode=mode)
     assert mask.dtype == np.int64
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), s.stats
+
+
+def test_config1_pysegmenter_256x512_vs_reference_python(oracle):
+    """BASELINE.json configs[0]: the 256x512 map the reference's utils/segmenter.py needs 169 s
+    for (options 0, 1/O, 0, prune 200) -- same instances from the GPU ObjectSegmenter."""
+    g = gu.load("py_synth_256x512_cfg1")
+    s = seg.ObjectSegmenter(g["class_probs"], g["sameness_probs"], 9, g["offsets"],
+                            seg.SegmenterOptions(*g["spec"]["opts"]))
+    mask, classes = s.run_segmentation()
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), s.stats
+    assert s.stats["certified"] == 1
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 2, 2), (1, 9, 3, 2), (9, 1, 3, 2), (13, 67, 5, 3), (31, 130, 3, 6)])
+def test_ragged_shapes_match_oracle(oracle, shape):
+    """Sizes that are not multiples of the tile/vector widths (N % 4 != 0, W < 64, single row or
+    column, offsets longer than the image) against the CPU oracle, both modes."""
+    H, W, C, O = shape
+    offs = synth.generate_offsets(max(2, min(H, W, 6)), max(2, O))[:O]
+    offs = [o for o in offs if o != (0, 0)]
+    s = synth.adversarial(H, W, C, offs, 4242 + H * W)
+    ref = oracle.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
+    ctx = seg.HostContext(H, W, C, len(offs))
+    try:
+        o = seg.default_options(mode=seg.MN_MODE_EXACT, clip_inputs=1)
+        mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+        assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+        o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1)
+        mask2, classes2, part2, st2 = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
+        # ROUNDS on adversarial data is not expected to reproduce the sequential order; it must
+        # still be a valid segmentation: dense labels, consistent counts, deterministic
+        assert mask2.min() >= 0 and mask2.max() == len(classes2)
+        assert st2["merges"] == H * W - st2["num_objects"]
+    finally:
+        ctx.close()
+
+
+def test_all_background_and_empty_class_list(oracle):
+    g = gu.load("cseg_closed_all_background")
+    mask, classes, part, stats = _run(g)
+    assert classes == [] and not mask.any()
+
+
+def test_same_different_bias_matches_oracle(oracle):
+    """same_different_bias != 0 is applied on load (the reference rewrites adj_pred in place,
+    segment.cc:183-195); the caller's array must stay untouched."""
+    g = gu.load("cseg_adv_24x24_o2")
+    before = g["sameness_probs"].copy()
+    mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT)
+    assert np.array_equal(before, g["sameness_probs"])
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
