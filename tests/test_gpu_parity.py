@@ -188,3 +188,27 @@ def test_same_different_bias_matches_oracle(oracle):
     mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT)
     assert np.array_equal(before, g["sameness_probs"])
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
+def test_config4_network_to_merger_device_resident(oracle):
+    """BASELINE.json configs[3]: PSPNet-ResNet50-shaped forward in PyTorch-ROCm feeding the HIP
+    merger without leaving the GPU; the merger's output on the network's maps equals the oracle's
+    (random weights give near-0.5, order-dependent maps: EXACT mode)."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from pspnet_pipeline import PSPNetResNet50, segment_image
+    H, W, C = 40, 56, 5
+    offs = synth.generate_offsets(8, 6)
+    torch.manual_seed(3)
+    model = PSPNetResNet50(C, len(offs), width=16).cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda")
+    merger = seg.Merger(H, W, C, len(offs))
+    opts = seg.default_options(clip_inputs=1, mode=seg.MN_MODE_EXACT)
+    mask, table, _, st = segment_image(model, img, offs, merger, opts)
+    with torch.no_grad():
+        probs = torch.sigmoid(model(img)[0]).float().cpu().numpy()
+    ref = oracle.run_csegment(probs[:C], probs[C:], C, offs, 0.0, 1.0, 0.03)
+    got = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
+    assert oracle.masks_equivalent(mask.cpu().numpy(), got, ref.mask, ref.object_class), st
+    merger.close()
