@@ -117,18 +117,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # instance-id match of rank 0's image against the reference's own result (golden vector)
-    id_match = None
-    if rank == 0:
-        golden = os.path.join(ROOT, "tests", "golden", "cseg_synth_1024x2048_cfg2.npz")
-        if os.path.exists(golden):
-            from oracle import checker as ck
-            z = np.load(golden)
-            got_cls = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
-            ok = ck.masks_equivalent(mask.cpu().numpy(), got_cls, z["mask"],
-                                     [int(c) for c in z["object_class"]])
-            id_match = {"vs": "reference segment.cc (golden vector, seed 1000)", "equal": bool(ok),
-                        "instances": st["num_instances"]}
+    # instance-id match of EVERY rank's image against the reference's own result for that image
+    # (golden vectors tests/golden/cseg_synth_1024x2048_*.npz, produced by the reference's
+    # segment.cc in 380-540 s per image); outside the timed region
+    from oracle import checker as ck
+    gname = "cseg_synth_1024x2048_cfg2.npz" if rank == 0 else "cseg_synth_1024x2048_s%d.npz" % (1000 + rank)
+    golden = os.path.join(ROOT, "tests", "golden", gname)
+    checked, equal = 0, 0
+    if os.path.exists(golden):
+        z = np.load(golden)
+        got_cls = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
+        checked = 1
+        equal = int(ck.masks_equivalent(mask.cpu().numpy(), got_cls, z["mask"],
+                                        [int(c) for c in z["object_class"]]))
+    if world > 1:
+        t = torch.tensor([checked, equal], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        checked, equal = int(t[0].item()), int(t[1].item())
+    id_match = {"vs": "reference segment.cc (golden vectors, seeds 1000+rank)",
+                "images_checked": checked, "images_equal": equal, "equal": bool(checked and checked == equal)}
 
     if rank == 0:
         avg_score_ms = sum(score_ms) / len(score_ms)

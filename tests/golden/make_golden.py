@@ -125,6 +125,13 @@ def cseg_specs(big: bool):
         for sd in (1001, 1002, 1003, 1004, 1005, 1006, 1007):   # images of ranks 1..7 (configs[2])
             specs.append(dict(name="cseg_synth_1024x2048_s%d" % sd, kind="synth", H=1024, W=2048,
                               C=9, offsets=[40, 10], seed=sd, noise=0.15, opts=(0.0, 1.0, 0.03)))
+        # BASELINE.json configs[4]: COCO-shape maps, 81 classes, extended offset set, occlusion
+        specs.append(dict(name="cseg_synth_400x667_c81", kind="synth", H=400, W=667, C=81,
+                          offsets=[80, 16], seed=1000, noise=0.15, occlusion=True,
+                          opts=(0.0, 1.0, 0.03)))
+        specs.append(dict(name="cseg_synth_800x1333_cfg5", kind="synth", H=800, W=1333, C=81,
+                          offsets=[80, 16], seed=1000, noise=0.15, occlusion=True,
+                          opts=(0.0, 1.0, 0.03)))
         for sd in (1000, 1001, 1002):  # the size the reference's own caller uses (segment.py:93)
             specs.append(dict(name="cseg_synth_512x1024_s%d" % sd, kind="synth", H=512, W=1024,
                               C=9, offsets=[40, 10], seed=sd, noise=0.15, opts=(0.0, 1.0, 0.03)))
