@@ -320,8 +320,11 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   else
     hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, 256)), dim3(256), 0, st, S, src, Rsrc, T);
   MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
+  // the compaction also scores the records for the coming round (best slot per object, band max)
+  MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)P.N * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
   hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S, T, L,
-                     c->cnt);
+                     c->fresh, c->aux, c->ball, c->gmax, c->cnt);
   MN_HIP(hipGetLastError());
   if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
   *Rout = c->h_cnt->n_records;
@@ -389,13 +392,10 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   }
   if (mode == MN_MODE_ROUNDS) {
     while (R > finish_limit && rounds < 5000) {
-      MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)N * sizeof(u64), st));
       MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
       MN_HIP(hipMemsetAsync(c->mate, 0xFF, (size_t)N * sizeof(int), st));
       MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records, any_selected, ...
       const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
-      MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
-      hipLaunchKernelGGL(mn_rec_score, g, b, 0, st, P, S, cur, R, c->fresh, c->aux, c->ball, c->gmax);
       hipLaunchKernelGGL(mn_band_threshold, dim3(1), dim3(64), 0, st, (const unsigned*)c->gmax,
                          P.bias, P.variant, band_gamma, c->theta);
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,

@@ -129,10 +129,17 @@ __global__ __launch_bounds__(256) void mn_build_from_pixels(ImgParams P, ObjStat
   }
 }
 
-// Table -> compact list; touched records get a fresh priority (they were re-keyed or folded).
-// A block owns 1024 consecutive slots and reserves its output range with ONE atomic.
+// Table -> compact list, fused with the scoring of the NEXT round: every record gets its fresh
+// priority (touched records take it as their stored priority, the others keep theirs unless it is
+// stale-high), the packed key goes into both endpoints' best slot, the block maximum feeds the
+// band threshold.  A block owns 1024 consecutive slots and reserves its output range with ONE
+// atomic.
 #define MN_COMPACT_SLOTS 1024
 __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashTab T, RecList L,
+                                                  float* __restrict__ fresh,
+                                                  unsigned char* __restrict__ aux,
+                                                  u64* __restrict__ ball,
+                                                  unsigned* __restrict__ gmax,
                                                   Counters* __restrict__ cnt) {
   __shared__ int sh_w[4][4];
   __shared__ int sh_base;
@@ -156,60 +163,39 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
     sh_base = tot ? atomicAdd(&cnt->n_records, tot) : 0;
   }
   __syncthreads();
+  unsigned mybits = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (key[j] == MN_EMPTY) continue;
     const unsigned slot = base + j * 256 + threadIdx.x;
     const i64 s = T.S[slot];
-    float st;
-    if (T.touched[slot]) {
-      int mc;
-      bool pos;
-      st = mn_score(P, S, mn_key_u(key[j]), mn_key_v(key[j]), mn_fixed_to_float(s), &mc, &pos);
-    } else {
-      st = T.st[slot];
-    }
+    const int u = mn_key_u(key[j]), v = mn_key_v(key[j]);
+    int mc;
+    bool pos;
+    const float f = mn_score(P, S, u, v, mn_fixed_to_float(s), &mc, &pos);
+    float st = T.touched[slot] ? f : T.st[slot];
+    if (st >= 0.0f && f < st) st = f;                 // stale-high: lowered right away
     const int idx = sh_base + sh_w[j][wave] + before[j];
     L.key[idx] = key[j];
     L.S[idx] = s;
     L.st[idx] = st;
-  }
-}
-
-// ---- rounds on the explicit record list -------------------------------------------------------
-
-// fresh priority of every record; eager refresh of stale-high records; best visible record per
-// object (ball = "best of all", with the record's gain>0 flag in the key).
-__global__ __launch_bounds__(256) void mn_rec_score(ImgParams P, ObjState S, RecList L, int R,
-                                                    float* __restrict__ fresh,
-                                                    unsigned char* __restrict__ aux,
-                                                    u64* __restrict__ ball,
-                                                    unsigned* __restrict__ gmax) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned mybits = 0;
-  if (i < R) {
-    const u64 key = L.key[i];
-    const int u = mn_key_u(key), v = mn_key_v(key);
-    int mc;
-    bool pos;
-    const float f = mn_score(P, S, u, v, mn_fixed_to_float(L.S[i]), &mc, &pos);
-    float st = L.st[i];
-    if (st >= 0.0f && f < st) { st = f; L.st[i] = f; }
-    fresh[i] = f;
-    aux[i] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // aux: merged class | gain>0 flag
+    fresh[idx] = f;
+    aux[idx] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // merged class | gain>0 flag
     if (st >= 0.0f) {
       // a plain look first: most records lose against what is already there (an object has tens
       // of records, a running maximum changes ~ln(n) times), and a lost race only costs the atomic
       const u64 ku = mn_pack(st, v, pos), kv = mn_pack(st, u, pos);
       if (ku > ball[u]) atomicMax(&ball[u], ku);
       if (kv > ball[v]) atomicMax(&ball[v], kv);
-      mybits = (st == 0.0f) ? 0u : __float_as_uint(st);
+      mybits = max(mybits, (st == 0.0f) ? 0u : __float_as_uint(st));
     }
   }
   // highest visible priority of the round (for the band threshold), spread over 64 words
   for (int off = 32; off > 0; off >>= 1) mybits = max(mybits, (unsigned)__shfl_xor((int)mybits, off));
-  if ((threadIdx.x & 63) == 0 && mybits) atomicMax(&gmax[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], mybits);
+  if (lane == 0 && mybits) atomicMax(&gmax[(blockIdx.x * 4 + wave) & 63], mybits);
 }
+
+// ---- rounds on the explicit record list -------------------------------------------------------
 
 // Band threshold of the round.  The reference pops records in globally descending priority; a
 // round may only merge records whose likelihood gain is within a factor `gamma` of the round's
