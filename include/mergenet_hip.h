@@ -64,10 +64,14 @@ typedef struct mn_options {
   int exact_limit;             /* AUTO: max initial records for exact mode (0 = default 32768)   */
   int finish_limit;            /* ROUNDS: hand over to the sequential finisher at <= this many
                                   live records (0 = default 8192)                                */
-  int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 16)         */
+  int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 32)         */
   float prune_threshold;       /* pysegmenter prune threshold (segmenter.py:351; default 200)    */
   int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) */
-  int reserved[4];
+  int no_handover_refresh;     /* ROUNDS: 1 = keep stored priorities when the finisher takes over  */
+  int band_permille;           /* ROUNDS: a round merges only records whose gain is >= this many
+                                  thousandths of the round's best gain (0 = default 100, <0 = off;
+                                  parity with the reference was lost at 10 and held from 25 up)   */
+  int reserved[2];
 } mn_options;
 
 typedef struct mn_stats {

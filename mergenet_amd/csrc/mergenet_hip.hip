@@ -43,7 +43,7 @@ struct mn_context {
   // records
   RecList LA, LB;
   float* fresh;
-  unsigned char *aux, *sel;
+  unsigned char* aux;
   int* touched_list;
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready;
@@ -135,7 +135,6 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->LB.st, R));
   MN_HIP(dev_alloc(c, &c->fresh, R));
   MN_HIP(dev_alloc(c, &c->aux, R));
-  MN_HIP(dev_alloc(c, &c->sel, R));
   MN_HIP(dev_alloc(c, &c->touched_list, R));
   MN_HIP(dev_alloc(c, &c->fin_lists, 3 * (size_t)MN_FIN2_MAXR));
   MN_HIP(dev_alloc(c, &c->T.key, cap));
@@ -189,7 +188,7 @@ extern "C" void mn_destroy(mn_context* c) {
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
-                 c->LB.key, c->LB.S, c->LB.st, c->fresh, c->aux, c->sel, c->touched_list, c->fin_lists, c->T.key,
+                 c->LB.key, c->LB.S, c->LB.st, c->fresh, c->aux, c->touched_list, c->fin_lists, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
                  c->bg_key, c->lp_out, c->gmax, c->theta, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
@@ -351,9 +350,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
   const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 8192;
-  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 16;
-  // reserved[1] (per mille) overrides the band factor for experiments; 0 = default
-  const float band_gamma = opts->reserved[1] > 0 ? opts->reserved[1] * 1e-3f : (opts->reserved[1] < 0 ? 0.0f : 0.1f);
+  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
+  const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
+                                                   : (opts->band_permille < 0 ? 0.0f : 0.1f);
   int mode = opts->mode;
   if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS)
     mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_ROUNDS;
@@ -423,7 +422,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
   {
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
-    if (mode == MN_MODE_ROUNDS && R > 0 && !opts->reserved[0])
+    if (mode == MN_MODE_ROUNDS && R > 0 && !opts->no_handover_refresh)
       hipLaunchKernelGGL(mn_rec_refresh, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R);
     if (R <= MN_FIN2_MAXR) {
       // record list resident in LDS (96 KiB dynamic); the (object -> record) map lives in `label`

@@ -2,19 +2,23 @@
 //
 // Reference work replaced: RunSegmentation + Merge (utils/csegment/segment.cc:539-727).  The
 // reference pops one record at a time from a priority queue; here every round
-//   1. re-scores all live records (fresh) next to their remembered (stored) priority,
-//   2. lets every object pick its best visible record (64-bit atomicMax of (priority, partner)),
-//   3. merges the records that are the best of BOTH endpoints -- a matching, so merges of one
-//      round never share an object -- and repeats 2-3 among still unmatched objects for records
-//      whose likelihood gain is positive,
-//   4. folds the records of absorbed objects into the survivors' records by re-inserting every
-//      record under its relabelled (min,max) key into an open-addressing table, log-odds summed
-//      in 2^-30 fixed point so that the sums do not depend on arrival order.
+//   1. has every live record scored (fresh) next to its remembered (stored) priority and the best
+//      visible record of every object found by a 64-bit atomicMax of (priority, gain>0, ~partner)
+//      -- fused into the compaction kernel of the previous round (mn_compact),
+//   2. computes the band threshold of the round (mn_band_threshold): only records whose gain is
+//      within a factor of the round's best gain may merge, which keeps the global descending
+//      order of the reference's queue to within that factor,
+//   3. pairs objects on the best-record forest (mn_obj_match_mutual / propose / accept): a
+//      matching, so the merges of one round never share an object,
+//   4. merges the pairs (mn_rec_apply) and folds the records of absorbed objects into the
+//      survivors' records by re-inserting every record under its relabelled (min,max) key into an
+//      open-addressing table (mn_rebuild), log-odds summed in 2^-30 fixed point so that the sums
+//      do not depend on arrival order.
 // Laziness is kept: a record remembers the priority it was last scored at (AdjacencyRecord::
 // merge_priority); only records incident to an absorbed object are re-scored by a merge
 // (segment.cc:650-707), a survivor's other records stay stale until selected ("popped",
-// segment.cc:554-565): stale-high ones are refreshed eagerly (order-neutral), stale-low ones keep
-// competing with their stored value and are refreshed instead of merged when selected.
+// segment.cc:554-565): stale-high ones are lowered eagerly, stale-low ones keep competing with
+// their stored value and are refreshed instead of merged when selected.
 #pragma once
 
 #include "mn_device.h"

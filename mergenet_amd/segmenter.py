@@ -41,7 +41,8 @@ class MnOptions(ctypes.Structure):
                 ("mode", ctypes.c_int), ("clip_inputs", ctypes.c_int),
                 ("exact_limit", ctypes.c_int), ("finish_limit", ctypes.c_int),
                 ("subrounds", ctypes.c_int), ("prune_threshold", ctypes.c_float),
-                ("compute_logprob", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
+                ("compute_logprob", ctypes.c_int), ("no_handover_refresh", ctypes.c_int),
+                ("band_permille", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
 
 
 class MnStats(ctypes.Structure):
