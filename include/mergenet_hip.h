@@ -151,6 +151,20 @@ void c_run_segmentation(float* class_pred, int class_dim, float* adj_pred, int o
                         int* output, int* object_class, float same_different_bias,
                         float object_merge_factor, float merge_logprob_bias);
 
+/* Producer hand-off on the device ("next" row 1 of the scope table): logits or probabilities
+ * [channels][in_h][in_w] -> probabilities [channels][out_h][out_w] in ONE pass: optional sigmoid
+ * (utils/inference_utils.py:44,96), bilinear resize with cv2.resize/INTER_LINEAR coordinates
+ * (egs/cityscape/local/segment.py:115-123) and the binding's clip (c_segment.pyx:53-55).  Replaces
+ * the .npy round trip between the network and the merger. */
+int mn_prepare_device(mn_context* ctx, const float* d_in, int channels, int in_height, int in_width,
+                      float* d_out, int out_height, int out_width, int apply_sigmoid, int clip,
+                      void* stream);
+
+/* Nearest-neighbour resize of the instance mask back to the image size, cv2 INTER_NEAREST
+ * coordinates (egs/cityscape/local/segment.py:146-149). */
+int mn_upsample_mask_device(mn_context* ctx, const int* d_mask, int in_height, int in_width,
+                            int* d_out, int out_height, int out_width, void* stream);
+
 int mn_last_status(void);
 const char* mn_status_string(int status);
 const char* mn_version(void);

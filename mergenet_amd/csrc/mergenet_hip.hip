@@ -16,6 +16,7 @@
 #include "mn_kernels_merge.h"
 #include "mn_kernels_finish.h"
 #include "mn_kernels_output.h"
+#include "mn_kernels_prepare.h"
 
 static thread_local int g_last_status = MN_OK;
 
@@ -613,4 +614,40 @@ extern "C" void c_run_segmentation(float* class_pred, int class_dim, float* adj_
                                  img_height, num_classes, offset_list, output, object_class, NULL,
                                  &o, NULL);
   if (rc != MN_OK) fprintf(stderr, "c_run_segmentation: %s\n", mn_status_string(rc));
+}
+
+
+// ---- producer hand-off / mask post-processing -----------------
+extern "C" int mn_prepare_device(mn_context* c, const float* d_in, int channels, int in_height,
+                                 int in_width, float* d_out, int out_height, int out_width,
+                                 int apply_sigmoid, int clip, void* stream) {
+  if (!c || !d_in || !d_out || channels <= 0 || in_height <= 0 || in_width <= 0 || out_height <= 0 ||
+      out_width <= 0 || out_height > 65535 || channels > 65535) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mn_prepare_maps, dim3(grid_for(out_width, 256), out_height, channels), dim3(256),
+                     0, st, d_in, channels, in_height, in_width, d_out, out_height, out_width,
+                     apply_sigmoid, clip);
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+extern "C" int mn_upsample_mask_device(mn_context* c, const int* d_mask, int in_height, int in_width,
+                                       int* d_out, int out_height, int out_width, void* stream) {
+  if (!c || !d_mask || !d_out || in_height <= 0 || in_width <= 0 || out_height <= 0 ||
+      out_width <= 0 || out_height > 65535) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mn_upsample_mask, dim3(grid_for(out_width, 256), out_height), dim3(256), 0, st,
+                     d_mask, in_height, in_width, d_out, out_height, out_width);
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
 }

@@ -1,0 +1,66 @@
+// mn_kernels_prepare.h -- producer hand-off and mask post-processing on the device
+// ("next" rows 1-2 of SURVEY.md section 8f).
+//
+// Reference work replaced (the Cityscapes caller, egs/cityscape/local/segment.py):
+//   F.sigmoid + .npy save        utils/inference_utils.py:44,96,122-126
+//   np.load + cv2.resize(..., seg_size) of [H,W,K] maps (bilinear, INTER_LINEAR)   segment.py:110-123
+//   the binding's clip            utils/csegment/c_segment.pyx:53-55
+//     -> mn_prepare_maps: logits or probabilities [K][Hin][Win] -> clipped probabilities
+//        [K][Hout][Wout], one pass, no host round trip
+//   cv2.resize(mask, original size, INTER_NEAREST)                                  segment.py:146-149
+//     -> mn_upsample_mask
+// Interpolation follows cv2's INTER_LINEAR for float images: source coordinate
+// (dst + 0.5) * scale - 0.5, clamped at both borders, horizontal then vertical blend in float32.
+// torch.nn.functional.interpolate(mode="bilinear", align_corners=False) uses the same mapping and
+// serves as the float reference in the tests (cv2 itself is not installed in this image).
+#pragma once
+
+#include "mn_device.h"
+
+__device__ __forceinline__ void mn_lin_coord(int d, float scale, int ssize, int* s0, int* s1, float* f) {
+  float fx = ((float)d + 0.5f) * scale - 0.5f;
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.0f; sx = 0; }
+  if (sx >= ssize - 1) { fx = 0.0f; sx = ssize - 1; }
+  *s0 = sx;
+  *s1 = min(sx + 1, ssize - 1);
+  *f = fx;
+}
+
+__global__ __launch_bounds__(256) void mn_prepare_maps(const float* __restrict__ in, int K, int Hin,
+                                                       int Win, float* __restrict__ out, int Hout,
+                                                       int Wout, int apply_sigmoid, int clip) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int k = blockIdx.z;
+  if (x >= Wout) return;
+  const float sx_scale = (float)Win / (float)Wout, sy_scale = (float)Hin / (float)Hout;
+  int x0, x1, y0, y1;
+  float fx, fy;
+  mn_lin_coord(x, sx_scale, Win, &x0, &x1, &fx);
+  mn_lin_coord(y, sy_scale, Hin, &y0, &y1, &fy);
+  const float* p = in + (size_t)k * Hin * Win;
+  float a = p[(size_t)y0 * Win + x0], b = p[(size_t)y0 * Win + x1];
+  float c = p[(size_t)y1 * Win + x0], d = p[(size_t)y1 * Win + x1];
+  if (apply_sigmoid) {
+    a = 1.0f / (1.0f + expf(-a)); b = 1.0f / (1.0f + expf(-b));
+    c = 1.0f / (1.0f + expf(-c)); d = 1.0f / (1.0f + expf(-d));
+  }
+  const float t0 = a * (1.0f - fx) + b * fx;
+  const float t1 = c * (1.0f - fx) + d * fx;
+  float v = t0 * (1.0f - fy) + t1 * fy;
+  if (clip) v = mn_clip(v);
+  out[((size_t)k * Hout + y) * Wout + x] = v;
+}
+
+// cv2 INTER_NEAREST: source index = min(floor(dst * src/dst_size), src - 1)
+__global__ __launch_bounds__(256) void mn_upsample_mask(const int* __restrict__ in, int Hin, int Win,
+                                                        int* __restrict__ out, int Hout, int Wout) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= Wout) return;
+  const int sx = min((int)floorf((float)x * ((float)Win / (float)Wout)), Win - 1);
+  const int sy = min((int)floorf((float)y * ((float)Hin / (float)Hout)), Hin - 1);
+  out[(size_t)y * Wout + x] = in[(size_t)sy * Win + sx];
+}

@@ -67,6 +67,7 @@ _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
            "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
+           "mn_prepare_device", "mn_upsample_mask_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -113,6 +114,14 @@ def load_library() -> ctypes.CDLL:
                                        ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float]
     lib.c_run_segmentation.restype = None
+    lib.mn_prepare_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.mn_prepare_device.restype = ctypes.c_int
+    lib.mn_upsample_mask_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p]
+    lib.mn_upsample_mask_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
     lib.mn_status_string.restype = ctypes.c_char_p
@@ -381,3 +390,36 @@ class Merger:
         if want_arrays:
             return a.value, b.value, cls, best
         return a.value, b.value
+
+
+    def prepare(self, maps, out_height: int, out_width: int, apply_sigmoid: bool = False,
+                clip: bool = True):
+        """Network output -> merger input on the device: optional sigmoid, bilinear resize with
+        cv2.resize coordinates (egs/cityscape/local/segment.py:115-123) and clip, one pass.
+        maps: float32 [K, Hin, Win] tensor on this GPU.  Returns float32 [K, out_height, out_width]."""
+        torch = self.torch
+        if not (maps.is_cuda and maps.dtype == torch.float32 and maps.is_contiguous() and maps.dim() == 3):
+            raise ValueError("expected a contiguous float32 [K,H,W] tensor on the GPU")
+        K, Hin, Win = maps.shape
+        out = torch.empty((K, out_height, out_width), dtype=torch.float32, device=maps.device)
+        stream = torch.cuda.current_stream(maps.device).cuda_stream
+        rc = self.lib.mn_prepare_device(self.handle, maps.data_ptr(), K, Hin, Win, out.data_ptr(),
+                                        out_height, out_width, int(apply_sigmoid), int(clip),
+                                        ctypes.c_void_p(stream))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return out
+
+    def upsample_mask(self, mask, out_height: int, out_width: int):
+        """Instance mask back to the image size, cv2 INTER_NEAREST coordinates (segment.py:146-149)."""
+        torch = self.torch
+        if not (mask.is_cuda and mask.dtype == torch.int32 and mask.is_contiguous() and mask.dim() == 2):
+            raise ValueError("expected a contiguous int32 [H,W] tensor on the GPU")
+        out = torch.empty((out_height, out_width), dtype=torch.int32, device=mask.device)
+        stream = torch.cuda.current_stream(mask.device).cuda_stream
+        rc = self.lib.mn_upsample_mask_device(self.handle, mask.data_ptr(), mask.shape[0],
+                                              mask.shape[1], out.data_ptr(), out_height, out_width,
+                                              ctypes.c_void_p(stream))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return out

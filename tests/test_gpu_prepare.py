@@ -1,0 +1,73 @@
+"""Producer hand-off and mask post-processing kernels against a plain PyTorch fp32 reference.
+
+Float kernel => torch reference (cv2 is not installed here): F.interpolate(mode="bilinear",
+align_corners=False) uses cv2.resize/INTER_LINEAR's coordinate mapping, mode="nearest" is cv2's
+INTER_NEAREST.  Tolerance: 2e-6 absolute on probabilities (float32 blend order differs).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [((19, 64, 96), (32, 48)), ((5, 50, 70), (25, 35)),
+                                   ((3, 33, 47), (64, 90)), ((2, 17, 9), (17, 9))])
+@pytest.mark.parametrize("sigmoid", [False, True])
+def test_prepare_matches_torch_bilinear(shape, sigmoid):
+    import torch
+    import torch.nn.functional as F
+    from mergenet_amd import segmenter as seg
+    (K, Hin, Win), (Ho, Wo) = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((K, Hin, Win), generator=g) * 3 if sigmoid else torch.rand((K, Hin, Win), generator=g)
+    x = x.cuda().contiguous()
+    m = seg.Merger(max(Hin, Ho), max(Win, Wo), 4, 4)
+    got = m.prepare(x, Ho, Wo, apply_sigmoid=sigmoid, clip=True)
+    src = torch.sigmoid(x) if sigmoid else x
+    ref = F.interpolate(src[None], size=(Ho, Wo), mode="bilinear", align_corners=False)[0]
+    eps = float(np.finfo(np.float32).eps)
+    ref = ref.clamp(eps, 1.0 - eps)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-6
+    m.close()
+
+
+@pytest.mark.parametrize("shape", [((32, 48), (64, 96)), ((25, 35), (50, 70)), ((40, 56), (37, 129))])
+def test_upsample_mask_matches_torch_nearest(shape):
+    import torch
+    import torch.nn.functional as F
+    from mergenet_amd import segmenter as seg
+    (Hin, Win), (Ho, Wo) = shape
+    g = torch.Generator().manual_seed(9)
+    mask = torch.randint(0, 50, (Hin, Win), generator=g, dtype=torch.int32).cuda()
+    m = seg.Merger(max(Hin, Ho), max(Win, Wo), 4, 4)
+    got = m.upsample_mask(mask, Ho, Wo)
+    ref = F.interpolate(mask[None, None].float(), size=(Ho, Wo), mode="nearest")[0, 0].to(torch.int32)
+    assert torch.equal(got, ref)
+    m.close()
+
+
+def test_prepare_then_segment_equals_host_pipeline(oracle):
+    """logits -> (device) sigmoid + resize + clip -> merger, against the same steps done with
+    torch on the host feeding the CPU oracle (the reference caller's order, segment.py:110-138)."""
+    import torch
+    import torch.nn.functional as F
+    from mergenet_amd import segmenter as seg, synth
+    offs = synth.generate_offsets(8, 6)
+    C, O = 4, len(offs)
+    s = synth.synth_v1(96, 128, C, offs, 77, num_instances=3)
+    probs = np.concatenate([s.class_probs, s.sameness_probs]).clip(1e-4, 1 - 1e-4)
+    logits = torch.from_numpy(np.log(probs / (1 - probs)).astype(np.float32)).cuda()
+    m = seg.Merger(96, 128, C, O)
+    maps = m.prepare(logits, 48, 64, apply_sigmoid=True, clip=True)
+    # the halved maps no longer match the offsets' geometry -> order-dependent input: EXACT mode
+    o = seg.default_options(mode=seg.MN_MODE_EXACT)
+    mask, table, _, st = m.segment(maps[:C].contiguous(), maps[C:].contiguous(), offs, o)
+    big = m.upsample_mask(mask, 96, 128)
+    host = maps.cpu().numpy()      # same bits as the merger saw (kernel already checked vs torch)
+    ref = oracle.run_csegment(host[:C], host[C:], C, offs, 0.0, 1.0, 0.03)
+    got = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
+    assert oracle.masks_equivalent(mask.cpu().numpy(), got, ref.mask, ref.object_class), st
+    ref_big = F.interpolate(torch.from_numpy(ref.mask)[None, None].float(), size=(96, 128), mode="nearest")[0, 0]
+    assert oracle.same_partition(big.cpu().numpy(), ref_big.numpy().astype(np.int32))
+    m.close()
