@@ -165,6 +165,13 @@ int mn_prepare_device(mn_context* ctx, const float* d_in, int channels, int in_h
 int mn_upsample_mask_device(mn_context* ctx, const int* d_mask, int in_height, int in_width,
                             int* d_out, int out_height, int out_width, void* stream);
 
+/* Run boundaries of ALL instances in one pass, for COCO RLE (egs/cityscape/local/segment.py:
+ * 165-186 encodes each instance with pycocotools over the Fortran-ordered binary mask).  The
+ * label scan runs column-major; d_points gets [positions | label before | label at] with stride
+ * `capacity`, *count the number of change points.  The host groups them per label. */
+int mn_rle_points_device(mn_context* ctx, const int* d_mask, int height, int width, int* d_points,
+                         int capacity, int* count, void* stream);
+
 int mn_last_status(void);
 const char* mn_status_string(int status);
 const char* mn_version(void);

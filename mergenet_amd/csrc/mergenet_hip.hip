@@ -651,3 +651,35 @@ extern "C" int mn_upsample_mask_device(mn_context* c, const int* d_mask, int in_
   g_last_status = MN_OK;
   return MN_OK;
 }
+
+
+// Change points of the column-major label scan (see mn_kernels_prepare.h).  d_points receives
+// 3 * count ints laid out as [positions | labels before | labels at] with stride `capacity`;
+// returns the count through *count (the call synchronises the stream), MN_ERR_CAPACITY if more
+// than `capacity` change points exist.
+extern "C" int mn_rle_points_device(mn_context* c, const int* d_mask, int height, int width,
+                                    int* d_points, int capacity, int* count, void* stream) {
+  if (!c || !d_mask || !d_points || !count || height <= 0 || width <= 0 || capacity <= 0 ||
+      (size_t)height * width > c->N) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = height * width;
+  const int nblk = (int)grid_for(N, MN_RLE_ITEMS);
+  hipLaunchKernelGGL(mn_rle_count, dim3(nblk), dim3(256), 0, st, d_mask, height, width, c->block_count);
+  hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 5);
+  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipStreamSynchronize(st));
+  const int total = c->h_scalars[5];
+  *count = total;
+  if (total > capacity) { g_last_status = MN_ERR_CAPACITY; return MN_ERR_CAPACITY; }
+  hipLaunchKernelGGL(mn_rle_scatter, dim3(nblk), dim3(256), 0, st, d_mask, height, width,
+                     (const int*)c->block_count, d_points, d_points + capacity,
+                     d_points + 2 * (size_t)capacity);
+  MN_HIP(hipGetLastError());
+  MN_HIP(hipStreamSynchronize(st));
+  g_last_status = MN_OK;
+  return MN_OK;
+}

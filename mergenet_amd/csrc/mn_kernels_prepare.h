@@ -64,3 +64,71 @@ __global__ __launch_bounds__(256) void mn_upsample_mask(const int* __restrict__ 
   const int sy = min((int)floorf((float)y * ((float)Hin / (float)Hout)), Hin - 1);
   out[(size_t)y * Wout + x] = in[(size_t)sy * Win + sx];
 }
+
+// ---- run boundaries of the instance mask in column-major order (COCO RLE) -----------------------
+// The reference encodes every instance with pycocotools' RLE over the Fortran-ordered binary mask
+// (egs/cityscape/local/segment.py:165-186: maskUtils.encode(np.asfortranarray(mask == i)), one
+// full-image pass per instance).  All instances' runs are delimited by the positions where the
+// label changes along the column-major scan, so ONE pass finds them: element j of the scan is
+// pixel (row j % H, column j / H); a change point is (j, label before, label at j).  They are
+// written in scan order (block counts -> mn_rank_scan -> scatter), the host groups them by
+// label and forms the counts / the compressed string.
+#define MN_RLE_ITEMS 1024
+
+__device__ __forceinline__ int mn_cm_label(const int* __restrict__ mask, int H, int W, int j) {
+  const int x = j / H, y = j - x * H;
+  return mask[(size_t)y * W + x];
+}
+
+__global__ __launch_bounds__(256) void mn_rle_count(const int* __restrict__ mask, int H, int W,
+                                                    int* __restrict__ block_count) {
+  __shared__ int sh[4];
+  const int N = H * W;
+  int c = 0;
+  for (int k = threadIdx.x; k < MN_RLE_ITEMS; k += 256) {
+    const int j = blockIdx.x * MN_RLE_ITEMS + k;
+    if (j < N) {
+      const int cur = mn_cm_label(mask, H, W, j);
+      const int prev = j > 0 ? mn_cm_label(mask, H, W, j - 1) : 0;
+      c += (cur != prev) ? 1 : 0;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void mn_rle_scatter(const int* __restrict__ mask, int H, int W,
+                                                      const int* __restrict__ block_offset,
+                                                      int* __restrict__ out_pos,
+                                                      int* __restrict__ out_prev,
+                                                      int* __restrict__ out_cur) {
+  __shared__ int sh_w[4];
+  const int N = H * W;
+  int running = block_offset[blockIdx.x];
+  for (int k0 = 0; k0 < MN_RLE_ITEMS; k0 += 256) {
+    const int j = blockIdx.x * MN_RLE_ITEMS + k0 + threadIdx.x;
+    int cur = 0, prev = 0;
+    if (j < N) {
+      cur = mn_cm_label(mask, H, W, j);
+      prev = j > 0 ? mn_cm_label(mask, H, W, j - 1) : 0;
+    }
+    const bool f = j < N && cur != prev;
+    const u64 m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh_w[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += sh_w[w];
+    const int tot = sh_w[0] + sh_w[1] + sh_w[2] + sh_w[3];
+    if (f) {
+      const int idx = running + woff + __popcll(m & ((1ull << lane) - 1ull));
+      out_pos[idx] = j;
+      out_prev[idx] = prev;
+      out_cur[idx] = cur;
+    }
+    running += tot;
+    __syncthreads();
+  }
+}

@@ -67,7 +67,7 @@ _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
            "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
-           "mn_prepare_device", "mn_upsample_mask_device",
+           "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -122,6 +122,9 @@ def load_library() -> ctypes.CDLL:
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p]
     lib.mn_upsample_mask_device.restype = ctypes.c_int
+    lib.mn_rle_points_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int, _i32p, ctypes.c_void_p]
+    lib.mn_rle_points_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
     lib.mn_status_string.restype = ctypes.c_char_p
@@ -423,3 +426,32 @@ class Merger:
         if rc != 0:
             raise MergeNetError(rc)
         return out
+
+
+    def encode_rle(self, mask, num_instances: int):
+        """COCO run-length encoding of every instance of an int32 [H,W] mask on this GPU.
+
+        Equivalent of ``[maskUtils.encode(np.asfortranarray(mask == i)) for i in 1..K]``
+        (egs/cityscape/local/segment.py:165-186) from ONE device pass over the mask; returns a list
+        of ``{"size": [H, W], "counts": bytes}`` with pycocotools' compressed counts string.
+        """
+        from . import rle
+        torch = self.torch
+        if not (mask.is_cuda and mask.dtype == torch.int32 and mask.is_contiguous() and mask.dim() == 2):
+            raise ValueError("expected a contiguous int32 [H,W] tensor on the GPU")
+        H, W = mask.shape
+        cap = max(1024, H * W // 4)
+        while True:
+            pts = torch.empty((3, cap), dtype=torch.int32, device=mask.device)
+            n = ctypes.c_int(0)
+            stream = torch.cuda.current_stream(mask.device).cuda_stream
+            rc = self.lib.mn_rle_points_device(self.handle, mask.data_ptr(), H, W, pts.data_ptr(), cap,
+                                               ctypes.byref(n), ctypes.c_void_p(stream))
+            if rc == -4 and n.value > cap:
+                cap = n.value
+                continue
+            if rc != 0:
+                raise MergeNetError(rc)
+            break
+        p = pts[:, : n.value].cpu().numpy()
+        return rle.from_change_points(p[0], p[1], p[2], H, W, num_instances)
