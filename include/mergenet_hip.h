@@ -172,6 +172,15 @@ int mn_upsample_mask_device(mn_context* ctx, const int* d_mask, int in_height, i
 int mn_rle_points_device(mn_context* ctx, const int* d_mask, int height, int width, int* d_points,
                          int capacity, int* count, void* stream);
 
+/* Sameness targets of an instance mask: out[k][r][c] = (mask[r+di][c+dj] == mask[r][c]), 1 outside
+ * the image (utils/dataset.py:259-277).  d_out is float32 [offset_dim][H][W]. */
+int mn_sameness_targets_device(mn_context* ctx, const int* d_mask, int height, int width,
+                               const int* offset_list, int offset_dim, float* d_out, void* stream);
+
+/* Confidence of the instances of the last mn_segment_device call: d_scores[k-1] = lp[cls] - lp[0]
+ * of label k (segment.h:109); the reference's COCO results carry a constant score 1. */
+int mn_instance_scores_device(mn_context* ctx, float* d_scores, void* stream);
+
 int mn_last_status(void);
 const char* mn_status_string(int status);
 const char* mn_version(void);

@@ -62,6 +62,8 @@ struct mn_context {
   int* h_scalars;         // pinned
   double* h_lp;           // pinned
   hipEvent_t ev[6];
+  ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
+  int last_valid;
   // staging for the host-pointer entry points
   float *d_class, *d_same;
   int *d_mask, *d_objcls, *d_part;
@@ -477,6 +479,8 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   }
   MN_HIP(hipEventRecord(c->ev[4], st));
   MN_HIP(hipGetLastError());
+  c->last_params = P;
+  c->last_valid = 1;
 
   MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -680,6 +684,40 @@ extern "C" int mn_rle_points_device(mn_context* c, const int* d_mask, int height
                      d_points + 2 * (size_t)capacity);
   MN_HIP(hipGetLastError());
   MN_HIP(hipStreamSynchronize(st));
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+
+extern "C" int mn_sameness_targets_device(mn_context* c, const int* d_mask, int height, int width,
+                                          const int* offset_list, int offset_dim, float* d_out,
+                                          void* stream) {
+  if (!c || !d_mask || !offset_list || !d_out || height <= 0 || width <= 0 || offset_dim <= 0 ||
+      offset_dim > MN_MAX_OFFSETS) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  MN_HIP(hipSetDevice(c->device));
+  ImgParams P;
+  memset(&P, 0, sizeof(P));
+  for (int k = 0; k < offset_dim; k++) { P.di[k] = offset_list[2 * k]; P.dj[k] = offset_list[2 * k + 1]; }
+  hipLaunchKernelGGL(mn_sameness_targets, dim3(grid_for((size_t)height * width, 256), offset_dim),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), d_mask, height, width, P, d_out);
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+// Confidence of the instances of the LAST mn_segment_device call on this context:
+// d_scores[k-1] = lp[cls] - lp[0] of label k (float32, at least num_instances entries).  The class
+// planes passed to that call must still be alive (objects that never merged read them).
+extern "C" int mn_instance_scores_device(mn_context* c, float* d_scores, void* stream) {
+  if (!c || !d_scores || !c->last_valid) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+  MN_HIP(hipSetDevice(c->device));
+  hipLaunchKernelGGL(mn_instance_scores, dim3(grid_for(c->last_params.N, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), c->last_params, obj_state(c),
+                     (const int*)c->label, d_scores);
+  MN_HIP(hipGetLastError());
   g_last_status = MN_OK;
   return MN_OK;
 }

@@ -132,3 +132,32 @@ __global__ __launch_bounds__(256) void mn_rle_scatter(const int* __restrict__ ma
     __syncthreads();
   }
 }
+
+// ---- sameness targets from an instance mask (training-side twin of the synthetic generator) ----
+// target[k][r][c] = (mask[r + di_k][c + dj_k] == mask[r][c]), 1 where the neighbour is outside the
+// image (utils/dataset.py:259-277: np.roll compare, border rows/columns forced to 1).
+__global__ __launch_bounds__(256) void mn_sameness_targets(const int* __restrict__ mask, int H, int W,
+                                                           ImgParams P, float* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (p >= H * W) return;
+  const int r = p / W, c = p - r * W;
+  const int rr = r + P.di[k], cc = c + P.dj[k];
+  float v = 1.0f;
+  if (rr >= 0 && rr < H && cc >= 0 && cc < W) v = (mask[(size_t)rr * W + cc] == mask[p]) ? 1.0f : 0.0f;
+  out[(size_t)k * H * W + p] = v;
+}
+
+// ---- per-instance confidence: log-prob margin of the instance class over background ------------
+// score[label - 1] = lp[cls] - lp[0] of the object (Object::GetNoBackLogprob, segment.h:109; the
+// reference's COCO results carry a constant score 1, egs/cityscape/local/segment.py:181).
+__global__ __launch_bounds__(256) void mn_instance_scores(ImgParams P, ObjState S,
+                                                          const int* __restrict__ label,
+                                                          float* __restrict__ scores) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N || S.parent[p] != p) return;
+  const int l = label[p];
+  if (l <= 0) return;
+  const bool valid = S.lpvalid[p] != 0;
+  scores[l - 1] = mn_obj_lp(P, S, valid, p, S.ocls[p]) - mn_obj_lp(P, S, valid, p, 0);
+}

@@ -67,7 +67,7 @@ _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
            "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
-           "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device",
+           "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -125,6 +125,12 @@ def load_library() -> ctypes.CDLL:
     lib.mn_rle_points_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int, _i32p, ctypes.c_void_p]
     lib.mn_rle_points_device.restype = ctypes.c_int
+    lib.mn_sameness_targets_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int, _i32p, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p]
+    lib.mn_sameness_targets_device.restype = ctypes.c_int
+    lib.mn_instance_scores_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_instance_scores_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
     lib.mn_status_string.restype = ctypes.c_char_p
@@ -455,3 +461,31 @@ class Merger:
             break
         p = pts[:, : n.value].cpu().numpy()
         return rle.from_change_points(p[0], p[1], p[2], H, W, num_instances)
+
+
+    def sameness_targets(self, mask, offsets):
+        """Instance mask int32 [H,W] -> float32 [O,H,W] sameness targets (utils/dataset.py:259-277)."""
+        torch = self.torch
+        if not (mask.is_cuda and mask.dtype == torch.int32 and mask.is_contiguous() and mask.dim() == 2):
+            raise ValueError("expected a contiguous int32 [H,W] tensor on the GPU")
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32).reshape(-1, 2))
+        H, W = mask.shape
+        out = torch.empty((off.shape[0], H, W), dtype=torch.float32, device=mask.device)
+        stream = torch.cuda.current_stream(mask.device).cuda_stream
+        rc = self.lib.mn_sameness_targets_device(self.handle, mask.data_ptr(), H, W,
+                                                 off.ctypes.data_as(_i32p), off.shape[0],
+                                                 out.data_ptr(), ctypes.c_void_p(stream))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return out
+
+    def instance_scores(self, num_instances: int, device=None):
+        """lp[cls] - lp[0] of each instance of the last segment() call (float32 [K])."""
+        torch = self.torch
+        dev = torch.device("cuda", self.device) if device is None else device
+        out = torch.zeros((max(1, num_instances),), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_instance_scores_device(self.handle, out.data_ptr(), ctypes.c_void_p(stream))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return out[:num_instances]

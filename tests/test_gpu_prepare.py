@@ -71,3 +71,50 @@ def test_prepare_then_segment_equals_host_pipeline(oracle):
     ref_big = F.interpolate(torch.from_numpy(ref.mask)[None, None].float(), size=(96, 128), mode="nearest")[0, 0]
     assert oracle.same_partition(big.cpu().numpy(), ref_big.numpy().astype(np.int32))
     m.close()
+
+
+def test_sameness_targets_match_numpy_roll_definition():
+    """np.roll compare with the border forced to 1, as utils/dataset.py:259-277 defines it."""
+    import torch
+    from mergenet_amd import segmenter as seg, synth
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    mask = rng.integers(0, 4, (H, W)).astype(np.int32)
+    offs = synth.generate_offsets(10, 6)
+    expect = np.zeros((len(offs), H, W), np.float32)
+    for n, (i, j) in enumerate(offs):
+        rolled = np.roll(np.roll(mask, -i, axis=0), -j, axis=1)
+        t = (rolled == mask)
+        if i < 0:
+            t[:-i, :] = 1
+        elif i > 0:
+            t[-i:, :] = 1
+        if j < 0:
+            t[:, :-j] = 1
+        elif j > 0:
+            t[:, -j:] = 1
+        expect[n] = t
+    m = seg.Merger(H, W, 4, len(offs))
+    got = m.sameness_targets(torch.from_numpy(mask).cuda(), offs).cpu().numpy()
+    assert np.array_equal(got, expect)
+    m.close()
+
+
+def test_instance_scores_are_the_class_margin(oracle):
+    import torch
+    from mergenet_amd import segmenter as seg, synth
+    offs = synth.generate_offsets(40, 10)
+    s = synth.synth_v1(64, 128, 9, offs, 1001, num_instances=4)
+    m = seg.Merger(64, 128, 9, len(offs))
+    cp, sp = torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()
+    mask, table, _, st = m.segment(cp, sp, offs, seg.default_options(clip_inputs=1))
+    K = st["num_instances"]
+    scores = m.instance_scores(K).cpu().numpy()
+    lp = np.log(s.class_probs.clip(np.finfo(np.float32).eps, 1 - np.finfo(np.float32).eps).astype(np.float64))
+    mk = mask.cpu().numpy()
+    tb = table.cpu().numpy()
+    for k in range(1, K + 1):
+        sel = mk == k
+        want = lp[tb[k - 1]][sel].sum() - lp[0][sel].sum()
+        assert abs(scores[k - 1] - want) <= 1e-4 * abs(want)
+    m.close()
