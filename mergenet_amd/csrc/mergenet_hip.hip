@@ -410,7 +410,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
       }
       hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
                          (const unsigned char*)c->aux, (const int*)c->mate, c->cnt);
-      size_t cap = next_pow2((size_t)R * 2 + 1024);
+      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);   // load <= 2/3
       if (cap > c->cap) cap = c->cap;
       int Rn = 0;
       rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn);

@@ -232,3 +232,42 @@ def test_rounds_mode_equals_oracle_on_many_seeds(oracle, noise):
             assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("opts", [(0.5, 1.0, 0.03), (-0.3, 0.5, 0.0), (0.0, 2.0, 0.1)])
+def test_rounds_mode_with_other_options_equals_oracle(oracle, opts):
+    """same_different_bias != 0 (applied on load), other merge factors and biases, ROUNDS mode."""
+    offs = synth.generate_offsets(40, 10)
+    s = synth.synth_v1(96, 160, 9, offs, 3100, noise=0.15, num_instances=4)
+    ref = oracle.run_csegment(s.class_probs, s.sameness_probs, 9, offs, *opts)
+    ctx = seg.HostContext(96, 160, 9, len(offs))
+    try:
+        o = seg.default_options(same_different_bias=opts[0], object_merge_factor=opts[1],
+                                merge_logprob_bias=opts[2], mode=seg.MN_MODE_ROUNDS, clip_inputs=1)
+        mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+        assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+    finally:
+        ctx.close()
+
+
+def test_one_context_serves_different_image_sizes(oracle):
+    """A context created for the largest image is reused for smaller ones and other offset sets."""
+    ctx = seg.HostContext(128, 256, 9, 10)
+    try:
+        for (H, W, C, oa, seed) in [(128, 256, 9, (40, 10), 1000), (32, 64, 9, (40, 10), 1000),
+                                    (24, 40, 3, (10, 6), 5), (128, 256, 9, (40, 10), 1000)]:
+            offs = synth.generate_offsets(*oa)
+            s = synth.synth_v1(H, W, C, offs, seed, num_instances=4 if H < 100 else None)
+            ref = oracle.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
+            mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs,
+                                                  seg.default_options(clip_inputs=1))
+            assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (H, W, st)
+    finally:
+        ctx.close()
+    big = seg.HostContext(16, 16, 3, 3)
+    with pytest.raises(seg.MergeNetError) as e:
+        big.segment(np.full((3, 32, 32), 0.5, np.float32), np.full((3, 32, 32), 0.5, np.float32),
+                    synth.generate_offsets(4, 3))
+    assert e.value.status == -4            # MN_ERR_CAPACITY
+    big.close()
