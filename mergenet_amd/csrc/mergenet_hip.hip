@@ -272,10 +272,15 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
   const dim3 gx(8 * ((grid_for(P.N, 256) + 7) / 8));
   const unsigned char* cls0 = c->ocls;       // unchanged until mn_pix_apply
   const unsigned char* matched = c->matched;
-  if (P.omf > 0.0f && P.sdb == 0.0f && P.O == 10)
-    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST>), gx, b, 0, st, P, cls0, matched, out);
-  else if (P.omf > 0.0f && P.sdb == 0.0f && P.O == 16)
-    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST>), gx, b, 0, st, P, cls0, matched, out);
+  const bool fast = P.omf > 0.0f && P.sdb == 0.0f;
+  if (fast && P.O == 10 && !P.clip)
+    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, false>), gx, b, 0, st, P, cls0, matched, out);
+  else if (fast && P.O == 10)
+    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, true>), gx, b, 0, st, P, cls0, matched, out);
+  else if (fast && P.O == 16 && !P.clip)
+    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, false>), gx, b, 0, st, P, cls0, matched, out);
+  else if (fast && P.O == 16)
+    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, true>), gx, b, 0, st, P, cls0, matched, out);
   else
     hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, obj_state(c), matched, out);
 }

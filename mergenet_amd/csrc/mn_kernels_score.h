@@ -127,7 +127,7 @@ __device__ __forceinline__ float mn_pixel_pair_prio(const ImgParams& P, int lo, 
   return (num + P.bias) / 1.0f;
 }
 
-template <int OT, bool FIRST>
+template <int OT, bool FIRST, bool CLIP>
 __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
                                                          const unsigned char* __restrict__ cls0,
                                                          const unsigned char* __restrict__ matched,
@@ -138,33 +138,44 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
   if (p >= P.N) return;
   if (!FIRST && matched[p]) { best_out[p] = 0; return; }
   const int r = p / P.W, c = p - r * P.W;
+  // stage 0: issue every load of the pixel (2*OT sameness values, 2*OT class bytes) before any of
+  // them is used -- the staging arrays are registers (compile-time OT, full unroll)
+  float val[2 * OT];
+  int nb[2 * OT];
+  unsigned char nbc[2 * OT];
   const int cp = cls0[p];
-  // pass 1 (branch-free): edges to pixels of the same class, ranked by (raw value, lower id)
-  // through one 64-bit max of (value bits << 32 | ~partner); values are in (0, 1], so their
-  // bit patterns order like the floats.
-  u64 bestkey = 0;
-  float diffmax = -1.0f;      // largest raw value on an edge across a class boundary
 #pragma unroll
   for (int k = 0; k < OT; k++) {
+    const float* __restrict__ plane = P.same + (size_t)k * P.N;
     const int di = P.di[k], dj = P.dj[k];
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
       const int rr = dir ? r - di : r + di;
       const int cc = dir ? c - dj : c + dj;
       const bool ok = (unsigned)rr < (unsigned)P.H && (unsigned)cc < (unsigned)P.W;
-      const int q = ok ? rr * P.W + cc : p;
-      const int src = dir ? q : p;
-      float v = P.same[(size_t)k * P.N + src];
-      if (P.clip) v = mn_clip(v);
-      const int cq = cls0[q];
+      const unsigned q = ok ? (unsigned)(rr * P.W + cc) : (unsigned)p;
+      val[2 * k + dir] = plane[dir ? q : (unsigned)p];
+      nbc[2 * k + dir] = cls0[q];
       bool live = ok;
       if (!FIRST) live = live && !matched[q];
-      const bool samec = live && cq == cp;
-      diffmax = (live && cq != cp) ? fmaxf(diffmax, v) : diffmax;
-      const u64 key = ((u64)__float_as_uint(v) << 32) | (u64)(0x7FFFFFFFu - (unsigned)q);
-      const u64 cand = samec ? key : 0ull;
-      bestkey = cand > bestkey ? cand : bestkey;
+      nb[2 * k + dir] = live ? (int)q : -1;
     }
+  }
+  // pass 1 (branch-free): edges to pixels of the same class, ranked by (raw value, lower id)
+  // through one 64-bit max of (value bits << 32 | ~partner); values are in (0, 1], so their
+  // bit patterns order like the floats.
+  u64 bestkey = 0;
+  float diffmax = -1.0f;      // largest raw value on an edge across a class boundary
+#pragma unroll
+  for (int e = 0; e < 2 * OT; e++) {
+    float v = val[e];
+    if (CLIP) v = mn_clip(v);
+    const bool live = nb[e] >= 0;
+    const bool samec = live && nbc[e] == cp;
+    diffmax = (live && nbc[e] != cp) ? fmaxf(diffmax, v) : diffmax;
+    const u64 key = ((u64)__float_as_uint(v) << 32) | (u64)(0x7FFFFFFFu - (unsigned)nb[e]);
+    const u64 cand = samec ? key : 0ull;
+    bestkey = cand > bestkey ? cand : bestkey;
   }
   const float bestv = bestkey ? __uint_as_float((unsigned)(bestkey >> 32)) : -1.0f;
   const int bestq = mn_pack_partner(bestkey);
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
       const int cq = cls0[q];
       if (cq == cp) continue;
       float v = P.same[(size_t)k * P.N + (dir ? q : p)];
-      if (P.clip) v = mn_clip(v);
+      if (CLIP) v = mn_clip(v);
       if (!(v >= vmin)) continue;
       bool pos;
       const int lo = min(p, q), hi = max(p, q);
