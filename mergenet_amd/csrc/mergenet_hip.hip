@@ -18,6 +18,8 @@
 #include "mn_kernels_output.h"
 #include "mn_kernels_prepare.h"
 
+#define MN_MAX_SUBROUNDS 64
+
 static thread_local int g_last_status = MN_OK;
 
 #define MN_HIP(expr)                                                                      \
@@ -56,6 +58,7 @@ struct mn_context {
   int* scalars;           // device: [0] violations, [1] total instances, [2] n_objects
   unsigned* gmax;         // device [64]: highest visible priority of the round
   float* theta;           // device [1]: band threshold of the round
+  int* progress;          // device [MN_MAX_SUBROUNDS]: did sub-round s pair anything
   u64* bg_key;            // device
   double* lp_out;         // device [4]
   Counters* h_cnt;        // pinned host mirror
@@ -150,6 +153,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->scalars, 8));
   MN_HIP(dev_alloc(c, &c->gmax, 64));
   MN_HIP(dev_alloc(c, &c->theta, 4));
+  MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
   MN_HIP(dev_alloc(c, &c->lp_out, 4));
   MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cnt), sizeof(Counters)));
@@ -193,7 +197,7 @@ extern "C" void mn_destroy(mn_context* c) {
                  c->label, c->mapbuf, c->lpsum, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
                  c->LB.key, c->LB.S, c->LB.st, c->fresh, c->aux, c->touched_list, c->fin_lists, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
-                 c->bg_key, c->lp_out, c->gmax, c->theta, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
+                 c->bg_key, c->lp_out, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -265,7 +269,8 @@ static ObjState obj_state(mn_context* c) {
 
 // edge pass dispatch: fast form for the common offset counts, generic form otherwise
 template <bool FIRST>
-static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, u64* out) {
+static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, u64* out, int s) {
+  const int* progress = c->progress;
   const dim3 g(grid_for(P.N, 256)), b(256);
   // XCD-banded tile order (mn_xcd_tile) unless a row is a whole number of 8-tile groups, in
   // which case the identity order already keeps every column band on one XCD (measured faster)
@@ -274,15 +279,19 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
   const unsigned char* matched = c->matched;
   const bool fast = P.omf > 0.0f && P.sdb == 0.0f;
   if (fast && P.O == 10 && !P.clip)
-    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, false>), gx, b, 0, st, P, cls0, matched, out);
+    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, false>), gx, b, 0, st, P, cls0, matched, out,
+                       progress, s);
   else if (fast && P.O == 10)
-    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, true>), gx, b, 0, st, P, cls0, matched, out);
+    hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, true>), gx, b, 0, st, P, cls0, matched, out,
+                       progress, s);
   else if (fast && P.O == 16 && !P.clip)
-    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, false>), gx, b, 0, st, P, cls0, matched, out);
+    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, false>), gx, b, 0, st, P, cls0, matched, out,
+                       progress, s);
   else if (fast && P.O == 16)
-    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, true>), gx, b, 0, st, P, cls0, matched, out);
+    hipLaunchKernelGGL((mn_edge_pass_fast<16, FIRST, true>), gx, b, 0, st, P, cls0, matched, out,
+                       progress, s);
   else
-    hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, obj_state(c), matched, out);
+    hipLaunchKernelGGL(mn_edge_pass_generic<FIRST>, g, b, 0, st, P, obj_state(c), matched, out, progress, s);
 }
 
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
@@ -299,7 +308,7 @@ static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool e
   }
   MN_HIP(hipEventRecord(c->ev[1], st));
   if (edge) {
-    launch_edge_pass<true>(c, P, st, c->ball);
+    launch_edge_pass<true>(c, P, st, c->ball, 0);
   }
   MN_HIP(hipEventRecord(c->ev[2], st));
   // the per-pixel arg-max is kept apart: ocls is overwritten as objects merge
@@ -358,7 +367,8 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
   const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 8192;
-  const int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
+  int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
+  if (subrounds > MN_MAX_SUBROUNDS) subrounds = MN_MAX_SUBROUNDS;
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
                                                    : (opts->band_permille < 0 ? 0.0f : 0.1f);
   int mode = opts->mode;
@@ -381,12 +391,13 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   int R = 0;
   if (mode == MN_MODE_ROUNDS) {
     // round 0 on the implicit pixel graph: matching sub-rounds, then one apply
+    MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
     hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                       (const u64*)c->ball, c->matched, c->mate);
+                       (const u64*)c->ball, c->matched, c->mate, c->progress, 0);
     for (int s = 1; s < subrounds; s++) {
-      launch_edge_pass<false>(c, P, st, c->bsub);
+      launch_edge_pass<false>(c, P, st, c->bsub, s);
       hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                         (const u64*)c->bsub, c->matched, c->mate);
+                         (const u64*)c->bsub, c->matched, c->mate, c->progress, s);
     }
     hipLaunchKernelGGL(mn_pix_apply, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
                        (const int*)c->mate, c->cnt);
@@ -405,13 +416,16 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
       const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
       hipLaunchKernelGGL(mn_band_threshold, dim3(1), dim3(64), 0, st, (const unsigned*)c->gmax,
                          P.bias, P.variant, band_gamma, c->theta);
+      MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
-                         (const float*)c->theta, c->matched, c->mate);
+                         (const float*)c->theta, c->matched, c->mate, c->progress);
       MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));   // accept cleans up after
       for (int s = 1; s < subrounds; s++) {
         hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
-                           (const float*)c->theta, (const unsigned char*)c->matched, c->bsub);
-        hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate);
+                           (const float*)c->theta, (const unsigned char*)c->matched, c->bsub,
+                           (const int*)c->progress, s);
+        hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate,
+                           c->progress, s);
       }
       hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
                          (const unsigned char*)c->aux, (const int*)c->mate, c->cnt);

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(256) void mn_init_objects(int N, int* __restrict__ 
 }
 
 // p and q merge when each is the other's best (mutually best record).
+// progress[s] is raised when sub-round s pairs anything; a sub-round that finds progress[s-1] == 0
+// returns at once (nothing changed, so it would reproduce the previous, empty, outcome).
 __global__ __launch_bounds__(256) void mn_pix_match(int N, const u64* __restrict__ best,
                                                     unsigned char* __restrict__ matched,
-                                                    int* __restrict__ mate) {
+                                                    int* __restrict__ mate,
+                                                    int* __restrict__ progress, int s) {
+  if (s > 0 && !progress[s - 1]) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
   const u64 b = best[p];
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void mn_pix_match(int N, const u64* __restrict
   if (bq == 0 || mn_pack_partner(bq) != p) return;
   matched[p] = 1;
   mate[p] = q;
+  progress[s] = 1;
 }
 
 // Merge of two single pixels: the lower id survives (equal sizes keep obj1, segment.cc:612-616).
@@ -232,7 +237,8 @@ __device__ __forceinline__ bool mn_in_band(u64 packed, float theta) {
 __global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __restrict__ ball,
                                                            const float* __restrict__ theta,
                                                            unsigned char* __restrict__ matched,
-                                                           int* __restrict__ mate) {
+                                                           int* __restrict__ mate,
+                                                           int* __restrict__ progress) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   const u64 b = ball[u];
@@ -242,12 +248,15 @@ __global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __r
   if (bt == 0 || mn_pack_partner(bt) != u) return;
   matched[u] = 1;
   mate[u] = t;
+  progress[0] = 1;
 }
 
 __global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restrict__ ball,
                                                       const float* __restrict__ theta,
                                                       const unsigned char* __restrict__ matched,
-                                                      u64* __restrict__ inbest) {
+                                                      u64* __restrict__ inbest,
+                                                      const int* __restrict__ progress, int s) {
+  if (!progress[s - 1]) return;        // the previous sub-round paired nothing: nothing can change
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N || matched[u]) return;
   const u64 b = ball[u];
@@ -261,7 +270,9 @@ __global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restri
 
 __global__ __launch_bounds__(256) void mn_obj_accept(int N, u64* __restrict__ inbest,
                                                      unsigned char* __restrict__ matched,
-                                                     int* __restrict__ mate) {
+                                                     int* __restrict__ mate,
+                                                     int* __restrict__ progress, int s) {
+  if (!progress[s - 1]) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
   const u64 k = inbest[t];
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void mn_obj_accept(int N, u64* __restrict__ in
   const int u = mn_pack_partner(k);
   matched[t] = 1; mate[t] = u;
   matched[u] = 1; mate[u] = t;
+  progress[s] = 1;
 }
 
 // Hand-over to the sequential finisher: every record gets its current priority.  The parallel

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void mn_class_pass(ImgParams P, unsigned char*
 template <bool FIRST>
 __global__ __launch_bounds__(256) void mn_edge_pass_generic(ImgParams P, ObjState S,
                                                     const unsigned char* __restrict__ matched,
-                                                    u64* __restrict__ best_out) {
+                                                    u64* __restrict__ best_out,
+                                                    const int* __restrict__ progress, int s) {
+  if (!FIRST && !progress[s - 1]) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.N) return;
   if (!FIRST && matched[p]) { best_out[p] = 0; return; }
@@ -131,7 +133,9 @@ template <int OT, bool FIRST, bool CLIP>
 __global__ __launch_bounds__(256) void mn_edge_pass_fast(ImgParams P,
                                                          const unsigned char* __restrict__ cls0,
                                                          const unsigned char* __restrict__ matched,
-                                                         u64* __restrict__ best_out) {
+                                                         u64* __restrict__ best_out,
+                                                         const int* __restrict__ progress, int s) {
+  if (!FIRST && !progress[s - 1]) return;   // previous sub-round paired nothing (see mn_pix_match)
   const int tile = mn_xcd_tile((P.N + 255) >> 8, P.banded);
   if (tile < 0) return;
   const int p = tile * 256 + threadIdx.x;

@@ -150,6 +150,6 @@ int main(int argc, char** argv) {
   timeit("no bytes/shifted/math", [&] { hipLaunchKernelGGL((edge_variant<10, 7>), g, b, 0, 0, P, d_c0, d_best); });
   timeit("banded full", [&] { hipLaunchKernelGGL((edge_variant<10, 8>), gx, b, 0, 0, P, d_c0, d_best); });
   timeit("vec4", [&] { hipLaunchKernelGGL((edge_vec4<10>), dim3((N / 4 + 255) / 256), b, 0, 0, P, d_c0, d_best); });
-  timeit("product kernel", [&] { hipLaunchKernelGGL((mn_edge_pass_fast<10, true, false>), gx, b, 0, 0, P, d_c0, (const unsigned char*)d_c0, d_best); });
+  timeit("product kernel", [&] { hipLaunchKernelGGL((mn_edge_pass_fast<10, true, false>), gx, b, 0, 0, P, d_c0, (const unsigned char*)d_c0, d_best, (const int*)nullptr, 0); });
   return 0;
 }
