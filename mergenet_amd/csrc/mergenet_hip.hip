@@ -45,8 +45,6 @@ struct mn_context {
   u64 *ball, *bsub;
   // records
   RecList LA, LB;
-  float* fresh;
-  unsigned char* aux;
   int* touched_list;
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready;
@@ -139,8 +137,10 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->LB.key, R));
   MN_HIP(dev_alloc(c, &c->LB.S, R));
   MN_HIP(dev_alloc(c, &c->LB.st, R));
-  MN_HIP(dev_alloc(c, &c->fresh, R));
-  MN_HIP(dev_alloc(c, &c->aux, R));
+  MN_HIP(dev_alloc(c, &c->LA.fr, R));
+  MN_HIP(dev_alloc(c, &c->LA.aux, R));
+  MN_HIP(dev_alloc(c, &c->LB.fr, R));
+  MN_HIP(dev_alloc(c, &c->LB.aux, R));
   MN_HIP(dev_alloc(c, &c->touched_list, R));
   MN_HIP(dev_alloc(c, &c->fin_lists, 3 * (size_t)MN_FIN2_MAXR));
   MN_HIP(dev_alloc(c, &c->T.key, cap));
@@ -195,7 +195,7 @@ extern "C" void mn_destroy(mn_context* c) {
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
-                 c->LB.key, c->LB.S, c->LB.st, c->fresh, c->aux, c->touched_list, c->fin_lists, c->T.key,
+                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
                  c->bg_key, c->lp_out, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
@@ -331,16 +331,18 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   MN_HIP(hipMemsetAsync(T.key, 0xFF, cap * sizeof(u64), st));
   MN_HIP(hipMemsetAsync(T.S, 0, cap * sizeof(i64), st));
   MN_HIP(hipMemsetAsync(T.touched, 0, cap, st));
+  // the next list is appended to by both kernels below; they also fill the best-record slots and
+  // the band maximum of the coming round
+  MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
+  MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)P.N * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
   if (from_pixels)
     hipLaunchKernelGGL(mn_build_from_pixels, dim3(grid_for(P.N, 256)), dim3(256), 0, st, P, S, T);
   else
-    hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, 256)), dim3(256), 0, st, S, src, Rsrc, T);
-  MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
-  // the compaction also scores the records for the coming round (best slot per object, band max)
-  MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)P.N * sizeof(u64), st));
-  MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, MN_REBUILD_ITEMS)), dim3(256), 0, st, S, src,
+                       Rsrc, (const unsigned char*)c->matched, T, L, c->ball, c->gmax, c->cnt);
   hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S, T, L,
-                     c->fresh, c->aux, c->ball, c->gmax, c->cnt);
+                     c->ball, c->gmax, c->cnt);
   MN_HIP(hipGetLastError());
   if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
   *Rout = c->h_cnt->n_records;
@@ -427,8 +429,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
         hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate,
                            c->progress, s);
       }
-      hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const float*)c->fresh,
-                         (const unsigned char*)c->aux, (const int*)c->mate, c->cnt);
+      hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const int*)c->mate, c->cnt);
       size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);   // load <= 2/3
       if (cap > c->cap) cap = c->cap;
       int Rn = 0;

@@ -27,6 +27,8 @@ struct RecList {
   u64* key;      // (u << 32) | v, u < v ; MN_EMPTY = dead
   i64* S;        // summed log-odds, 2^-30 fixed point   (AdjacencyRecord::obj_merge_logprob)
   float* st;     // stored priority                      (AdjacencyRecord::merge_priority)
+  float* fr;     // priority under the objects' current state (scored when the list is built)
+  unsigned char* aux;   // merged class (7 bits) | likelihood gain > 0 (bit 7)
 };
 
 struct HashTab {
@@ -145,8 +147,6 @@ __global__ __launch_bounds__(256) void mn_build_from_pixels(ImgParams P, ObjStat
 // atomic.
 #define MN_COMPACT_SLOTS 1024
 __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashTab T, RecList L,
-                                                  float* __restrict__ fresh,
-                                                  unsigned char* __restrict__ aux,
                                                   u64* __restrict__ ball,
                                                   unsigned* __restrict__ gmax,
                                                   Counters* __restrict__ cnt) {
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
     L.key[idx] = key[j];
     L.S[idx] = s;
     L.st[idx] = st;
-    fresh[idx] = f;
-    aux[idx] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));   // merged class | gain>0 flag
+    L.fr[idx] = f;
+    L.aux[idx] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));
     if (st >= 0.0f) {
       // a plain look first: most records lose against what is already there (an object has tens
       // of records, a running maximum changes ~ln(n) times), and a lost race only costs the atomic
@@ -301,8 +301,6 @@ __global__ __launch_bounds__(256) void mn_rec_refresh(ImgParams P, ObjState S, R
 
 // Selected records: refresh (stale-low) or merge (segment.cc:560-565, 602-642).
 __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, RecList L, int R,
-                                                    const float* __restrict__ fresh,
-                                                    const unsigned char* __restrict__ aux,
                                                     const int* __restrict__ mate,
                                                     Counters* __restrict__ cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,7 +308,7 @@ __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, Rec
   const u64 key0 = L.key[i];
   if (mate[mn_key_u(key0)] != mn_key_v(key0)) return;     // not the record of a matched pair
   cnt->any_selected = 1;
-  const float f = fresh[i], st = L.st[i];
+  const float f = L.fr[i], st = L.st[i];
   // csegment merges when the re-scored priority equals the popped one (segment.cc:561); a
   // record whose priority rose since it was stored is re-queued with the new value instead.
   // pysegmenter merges on >= (segmenter.py:470).
@@ -323,21 +321,81 @@ __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, Rec
   for (int c = 0; c < P.C; c++)
     S.lpsum[(size_t)c * P.N + a] = mn_obj_lp(P, S, va, a, c) + mn_obj_lp(P, S, vb, b, c);
   S.lpvalid[a] = 1;
-  S.ocls[a] = (unsigned char)(aux[i] & 0x7F);
+  S.ocls[a] = (unsigned char)(L.aux[i] & 0x7F);
   S.osize[a] = na + nb;
   S.parent[b] = a;
 }
 
-// Re-insert every record under its relabelled key; records inside one object disappear.
-__global__ __launch_bounds__(256) void mn_rebuild(ObjState S, RecList L, int R, HashTab T) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  const u64 key = L.key[i];
-  if (key == MN_EMPTY) return;
-  const int u = mn_key_u(key), v = mn_key_v(key);
-  const int nu = S.parent[u], nv = S.parent[v];
-  if (nu == nv) return;
-  const unsigned slot = mn_tab_insert(T, mn_key(nu, nv), L.S[i]);
-  if (nu != u || nv != v) T.touched[slot] = 1;   // incident to an absorbed object: re-score
-  else T.st[slot] = L.st[i];                     // untouched: keeps its stored priority
+// Records of the finished round -> table / next list.  A record whose endpoints both sat the round
+// out ("idle": neither matched) cannot change -- same key, same log-odds, same object state, hence
+// the same fresh priority, and nothing can fold into it, because a fold needs a survivor at one
+// end -- so it goes straight to the next list (block-aggregated append) together with its entry
+// for the next round's best-record slots; only the others are re-inserted under their relabelled
+// key (records inside one object disappear there).
+#define MN_REBUILD_ITEMS 1024
+__global__ __launch_bounds__(256) void mn_rebuild(ObjState S, RecList L, int R,
+                                                  const unsigned char* __restrict__ matched,
+                                                  HashTab T, RecList Out, u64* __restrict__ ball,
+                                                  unsigned* __restrict__ gmax,
+                                                  Counters* __restrict__ cnt) {
+  __shared__ int sh_w[4][4];
+  __shared__ int sh_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * MN_REBUILD_ITEMS;
+  u64 key[4];
+  int before[4];
+  bool idle[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = base + j * 256 + threadIdx.x;
+    key[j] = i < R ? L.key[i] : MN_EMPTY;
+    idle[j] = false;
+    if (key[j] != MN_EMPTY) {
+      const int u = mn_key_u(key[j]), v = mn_key_v(key[j]);
+      idle[j] = !matched[u] && !matched[v];
+      if (!idle[j]) {
+        const int nu = S.parent[u], nv = S.parent[v];
+        if (nu != nv) {
+          const unsigned slot = mn_tab_insert(T, mn_key(nu, nv), L.S[i]);
+          if (nu != u || nv != v) T.touched[slot] = 1;   // incident to an absorbed object: re-score
+          else T.st[slot] = L.st[i];                     // keeps its stored priority
+        }
+      }
+    }
+    const u64 m = __ballot(idle[j]);
+    before[j] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sh_w[j][wave] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int j = 0; j < 4; j++)
+      for (int w = 0; w < 4; w++) { const int t = sh_w[j][w]; sh_w[j][w] = tot; tot += t; }
+    sh_base = tot ? atomicAdd(&cnt->n_records, tot) : 0;
+  }
+  __syncthreads();
+  unsigned mybits = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (!idle[j]) continue;
+    const int i = base + j * 256 + threadIdx.x;
+    const int idx = sh_base + sh_w[j][wave] + before[j];
+    const float st = L.st[i];
+    const unsigned char ax = L.aux[i];
+    Out.key[idx] = key[j];
+    Out.S[idx] = L.S[i];
+    Out.st[idx] = st;
+    Out.fr[idx] = L.fr[i];
+    Out.aux[idx] = ax;
+    if (st >= 0.0f) {
+      const int u = mn_key_u(key[j]), v = mn_key_v(key[j]);
+      const bool pos = (ax & 0x80) != 0;
+      const u64 ku = mn_pack(st, v, pos), kv = mn_pack(st, u, pos);
+      if (ku > ball[u]) atomicMax(&ball[u], ku);
+      if (kv > ball[v]) atomicMax(&ball[v], kv);
+      mybits = max(mybits, (st == 0.0f) ? 0u : __float_as_uint(st));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mybits = max(mybits, (unsigned)__shfl_xor((int)mybits, off));
+  if (lane == 0 && mybits) atomicMax(&gmax[(blockIdx.x * 4 + wave) & 63], mybits);
 }
