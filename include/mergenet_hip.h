@@ -63,14 +63,14 @@ typedef struct mn_options {
   int clip_inputs;             /* 1: clip to [2^-23, 1-2^-23] on load (c_segment.pyx:53-55 fused) */
   int exact_limit;             /* AUTO: max initial records for exact mode (0 = default 32768)   */
   int finish_limit;            /* ROUNDS: hand over to the sequential finisher at <= this many
-                                  live records (0 = default 8192)                                */
+                                  live records (0 = default 4096)                                */
   int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 32)         */
   float prune_threshold;       /* pysegmenter prune threshold (segmenter.py:351; default 200)    */
   int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) */
   int no_handover_refresh;     /* ROUNDS: 1 = keep stored priorities when the finisher takes over  */
   int band_permille;           /* ROUNDS: a round merges only records whose gain is >= this many
                                   thousandths of the round's best gain (0 = default 100, <0 = off;
-                                  parity with the reference was lost at 10 and held from 25 up)   */
+                                  parity with the reference was lost at 10, once in 65 runs at 25, never from 50 up)   */
   int reserved[2];
 } mn_options;
 

@@ -368,7 +368,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   const int N = P.N;
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
-  const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 8192;
+  const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 4096;
   int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
   if (subrounds > MN_MAX_SUBROUNDS) subrounds = MN_MAX_SUBROUNDS;
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
@@ -422,7 +422,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
                          (const float*)c->theta, c->matched, c->mate, c->progress);
       MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));   // accept cleans up after
-      for (int s = 1; s < subrounds; s++) {
+      // late rounds are launch-bound: fewer matching sub-rounds once the list is small
+      const int sub_r = R > (1 << 20) ? subrounds : (subrounds > 8 ? subrounds / 4 : subrounds);
+      for (int s = 1; s < sub_r; s++) {
         hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
                            (const float*)c->theta, (const unsigned char*)c->matched, c->bsub,
                            (const int*)c->progress, s);

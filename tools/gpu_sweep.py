@@ -9,8 +9,8 @@ for name in sys.argv[1:]:
   g = gu.load(name)
   H, W, C = g["spec"]["H"], g["spec"]["W"], g["spec"]["C"]
   ctx = seg.HostContext(H, W, C, len(g["offsets"]))
-  for norefresh in (10, 5, 2, 1):     # here: band factor in per mille (-1 = no band)
-   for sub, fin in [(16, 8192), (32, 8192), (8, 8192), (4, 8192)]:
+  for norefresh in (100, 50, 25):     # here: band factor in per mille (-1 = no band)
+   for sub, fin in [(32, 8192), (16, 8192), (8, 8192), (32, 4096), (64, 8192)]:
     o = seg.default_options(mode=seg.MN_MODE_ROUNDS, subrounds=sub, finish_limit=fin)
     o.band_permille = norefresh
     mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
