@@ -273,3 +273,50 @@ def test_one_context_serves_different_image_sizes(oracle):
                     synth.generate_offsets(4, 3))
     assert e.value.status == -4            # MN_ERR_CAPACITY
     big.close()
+
+
+def test_fuzz_exact_mode_equals_oracle_on_random_small_inputs(oracle):
+    """60 random tiny problems (continuous random maps: no ties): random sizes, class counts,
+    offset lists and options; EXACT mode must reproduce the oracle's partition, classes and
+    log-likelihood on every one."""
+    rng = np.random.default_rng(20261003)
+    bad = []
+    for it in range(60):
+        H, W = int(rng.integers(2, 20)), int(rng.integers(2, 24))
+        C = int(rng.integers(1, 7))
+        O = int(rng.integers(1, 7))
+        offs = []
+        while len(offs) < O:
+            o = (int(rng.integers(-5, 6)), int(rng.integers(-5, 6)))
+            if o == (0, 0) or o in offs or (-o[0], -o[1]) in offs:
+                continue
+            offs.append(o)
+        cp = rng.uniform(0.02, 0.98, (C, H, W)).astype(np.float32)
+        sp = rng.uniform(0.02, 0.98, (O, H, W)).astype(np.float32)
+        opts = (float(rng.choice([0.0, 0.0, 0.4, -0.3])), float(rng.choice([1.0, 0.25, 0.5, 2.0])),
+                float(rng.choice([0.0, 0.03, 0.1, -0.05])))
+        ref = oracle.run_csegment(cp, sp, C, offs, *opts)
+        ctx = seg.HostContext(H, W, C, O)
+        try:
+            o = seg.default_options(same_different_bias=opts[0], object_merge_factor=opts[1],
+                                    merge_logprob_bias=opts[2], mode=seg.MN_MODE_EXACT)
+            mask, classes, part, st = ctx.segment(cp, sp, offs, o)
+        finally:
+            ctx.close()
+        ok = oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class) and \
+            oracle.same_partition(part, ref.partition) and \
+            abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+        if not ok:
+            bad.append((it, H, W, C, offs, opts))
+    assert not bad, bad
+
+
+def test_abi_entry_regrows_its_cached_context(oracle):
+    """c_run_segmentation keeps one context per thread and re-creates it for larger images."""
+    for name in ("cseg_closed_two_halves", "cseg_synth_32x64_n15", "cseg_adv_16x16_o0",
+                 "cseg_synth_64x128_n15", "cseg_closed_single_instance"):
+        g = gu.load(name)
+        mask, classes = seg.run_segmentation(np.ascontiguousarray(g["class_probs"]),
+                                             np.ascontiguousarray(g["sameness_probs"]),
+                                             g["spec"]["C"], list(g["offsets"]), *g["spec"]["opts"])
+        assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), name
