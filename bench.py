@@ -120,7 +120,7 @@ def main():
     # instance-id match of EVERY rank's image against the reference's own result for that image
     # (golden vectors tests/golden/cseg_synth_1024x2048_*.npz, produced by the reference's
     # segment.cc in 380-540 s per image); outside the timed region
-    from oracle import checker as ck
+    from mergenet_amd import labels as ck      # plain numpy label-map comparison
     gname = "cseg_synth_1024x2048_cfg2.npz" if rank == 0 else "cseg_synth_1024x2048_s%d.npz" % (1000 + rank)
     golden = os.path.join(ROOT, "tests", "golden", gname)
     checked, equal = 0, 0

@@ -219,7 +219,7 @@ def test_rounds_mode_equals_oracle_on_many_seeds(oracle, noise):
     """ROUNDS mode against the CPU oracle run on the box: 8 seeds per noise level at 128x256
     (4-5 instances each, C=9, O=10, Cityscapes options); every partition, class list and
     log-likelihood must agree.  Noise <= 0.35 keeps intra-instance edges above p = 0.5 (the
-    certified regime); 0.45 is beyond it (tools/gpu_noise_study.py: 8/8 equal up to noise 0.5,
+    certified regime); 0.45 is beyond it (tests/tools/gpu_noise_study.py: 8/8 equal up to noise 0.5,
     7/8 at 0.6 where the eighth has a HIGHER likelihood than the reference's result)."""
     offs = synth.generate_offsets(40, 10)
     ctx = seg.HostContext(128, 256, 9, len(offs))
