@@ -12,6 +12,7 @@ from multiprocessing import Pool
 H, W, C = (int(sys.argv[1]), int(sys.argv[2])) + (9,) if len(sys.argv) > 2 else (512, 1024, 9)
 SEEDS = list(range(int(sys.argv[3]) if len(sys.argv) > 3 else 2000, (int(sys.argv[3]) if len(sys.argv) > 3 else 2000) + (int(sys.argv[4]) if len(sys.argv) > 4 else 16)))
 NOISE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.15
+VARIANT = sys.argv[6] if len(sys.argv) > 6 else "csegment"     # or "pysegmenter" (options 0, 1/O, 0)
 
 
 def oracle_one(seed):
@@ -20,7 +21,10 @@ def oracle_one(seed):
     offs = synth.generate_offsets(40, 10)
     s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE)
     t = time.time()
-    r = ck.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
+    if VARIANT == "pysegmenter":
+        r = ck.run_pysegmenter(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0 / len(offs), 0.0)
+    else:
+        r = ck.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
     return seed, r.mask, r.object_class, r.total_logprob, time.time() - t
 
 
@@ -33,7 +37,12 @@ if __name__ == "__main__":
         gpu = {}
         for seed in SEEDS:
             s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE)
-            mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, seg.default_options(mode=seg.MN_MODE_ROUNDS))
+            if VARIANT == "pysegmenter":
+                o = seg.default_options(mode=seg.MN_MODE_ROUNDS, variant=seg.MN_VARIANT_PYSEGMENTER,
+                                        object_merge_factor=1.0 / len(offs), merge_logprob_bias=0.0)
+            else:
+                o = seg.default_options(mode=seg.MN_MODE_ROUNDS)
+            mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
             gpu[seed] = (mask, classes, st)
         while not pending.ready():
             print("waiting for the CPU oracle ...", flush=True)
@@ -47,4 +56,4 @@ if __name__ == "__main__":
         print("seed %d: %s  instances gpu %d ref %d  certified %d  gpu %.1f ms  oracle %.0f s  rel.loglik diff %.1e"
               % (seed, "EQUAL" if ok else "DIFFERENT", len(classes), len(rcls), st["certified"], st["ms_total"], dt,
                  abs(st["total_logprob"] - rlp) / abs(rlp)), flush=True)
-    print("parity campaign %dx%d noise %.2f: %d/%d images identical to the sequential reference order" % (H, W, NOISE, eq, len(SEEDS)))
+    print("parity campaign %s %dx%d noise %.2f: %d/%d images identical to the sequential reference order" % (VARIANT, H, W, NOISE, eq, len(SEEDS)))
