@@ -49,9 +49,14 @@ enum mn_variant {
 };
 
 enum mn_mode {
-  MN_MODE_AUTO = 0,      /* exact when the image has <= exact_limit initial records, else rounds */
+  MN_MODE_AUTO = 0,      /* EXACT when the image has <= exact_limit initial records, else
+                            COMPONENTS                                                           */
   MN_MODE_EXACT = 1,     /* sequential lazy-greedy order on the GPU (one workgroup)              */
-  MN_MODE_ROUNDS = 2     /* parallel rounds + sequential finisher + certificate                  */
+  MN_MODE_ROUNDS = 2,    /* parallel rounds + sequential finisher + certificate                  */
+  MN_MODE_COMPONENTS = 3 /* sign-separable inputs: phase 1 of the merge (provably order-
+                            independent there) by one union-find sweep over the positive edges,
+                            then rounds/finisher on the records between components; falls back to
+                            ROUNDS when the input is not sign-separable (mode_used tells)         */
 };
 
 typedef struct mn_options {

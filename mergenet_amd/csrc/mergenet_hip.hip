@@ -17,6 +17,7 @@
 #include "mn_kernels_finish.h"
 #include "mn_kernels_output.h"
 #include "mn_kernels_prepare.h"
+#include "mn_kernels_cc.h"
 
 #define MN_MAX_SUBROUNDS 64
 
@@ -37,11 +38,13 @@ struct mn_context {
   int device;
   int maxH, maxW, maxC, maxO;
   size_t N, Rmax, cap;
+  size_t cc_cap;          // table capacity used by the last component contraction
   size_t bytes;
   // objects
   unsigned char *ocls, *cls0, *lpvalid, *matched, *pruned;
   int *osize, *parent, *mate, *root, *label, *mapbuf;
   float* lpsum;
+  i64* lp_acc;            // [C][N] fixed-point class log-prob sums of the component contraction
   u64 *ball, *bsub;
   // records
   RecList LA, LB;
@@ -129,6 +132,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->label, N));
   MN_HIP(dev_alloc(c, &c->mapbuf, N));
   MN_HIP(dev_alloc(c, &c->lpsum, N * (size_t)c->maxC));
+  MN_HIP(dev_alloc(c, &c->lp_acc, N * (size_t)c->maxC));
   MN_HIP(dev_alloc(c, &c->ball, N));
   MN_HIP(dev_alloc(c, &c->bsub, N));
   MN_HIP(dev_alloc(c, &c->LA.key, R));
@@ -194,7 +198,7 @@ extern "C" void mn_destroy(mn_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
-                 c->label, c->mapbuf, c->lpsum, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
+                 c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
                  c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
                  c->bg_key, c->lp_out, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
@@ -349,6 +353,51 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   return MN_OK;
 }
 
+// Component contraction (mn_kernels_cc.h).  Precondition: objects initialised, class pass done.
+// Returns 0 when the input is sign-separable (object state + table of records between components
+// ready), 1 when it is not (caller falls back), < 0 on error.
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, long long R0) {
+  const int N = P.N;
+  ObjState S = obj_state(c);
+  const dim3 b(256), gx(8 * ((grid_for(N, 256) + 7) / 8));
+  // row stage on the (0, +1) offset if the list has it (generate_offsets always does), then the
+  // shortest offsets first: they connect almost everything
+  for (int k = 0; k < P.O; k++)
+    if (P.di[k] == 0 && P.dj[k] == 1) {
+      hipLaunchKernelGGL(mn_cc_rows, dim3(grid_for(N, 256)), b, 0, st, P, c->parent, k);
+      break;
+    }
+  int ksplit = P.O < 2 ? P.O : 2;
+  hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
+  hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, c->parent);
+  if (ksplit < P.O) {
+    hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, ksplit, P.O);
+    hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, c->parent);
+  }
+  MN_HIP(hipMemsetAsync(c->osize, 0, (size_t)N * sizeof(int), st));
+  MN_HIP(hipMemsetAsync(c->lp_acc, 0, (size_t)N * P.C * sizeof(i64), st));
+  MN_HIP(hipMemsetAsync(c->scalars + 6, 0, sizeof(int), st));
+  size_t cap = next_pow2((size_t)R0 / 8 + 4096);      // records between components are few
+  if (cap > c->cap) cap = c->cap;
+  c->cc_cap = cap;
+  HashTab T = c->T;
+  T.mask = (unsigned)(cap - 1);
+  MN_HIP(hipMemsetAsync(T.key, 0xFF, cap * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(T.S, 0, cap * sizeof(i64), st));
+  MN_HIP(hipMemsetAsync(T.touched, 0, cap, st));
+  const unsigned waves = grid_for(N, MN_CC_CHUNK);
+  hipLaunchKernelGGL(mn_cc_sums, dim3(grid_for((size_t)waves * 64, 256)), b, 0, st, P, S,
+                     (const unsigned char*)c->cls0, c->lp_acc, c->scalars + 6);
+  hipLaunchKernelGGL(mn_cc_edges, gx, b, 0, st, P, S, T, c->scalars + 6);
+  MN_HIP(hipGetLastError());
+  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipStreamSynchronize(st));
+  if (c->h_scalars[6] != 0) return 1;
+  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc);
+  MN_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int class_dim,
                                  const float* d_adj_pred, int offset_dim, int W, int H,
                                  int num_classes, const int* offset_list, int* d_mask,
@@ -374,8 +423,16 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
                                                    : (opts->band_permille < 0 ? 0.0f : 0.1f);
   int mode = opts->mode;
-  if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS)
-    mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_ROUNDS;
+  if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS && mode != MN_MODE_COMPONENTS)
+    mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_COMPONENTS;
+  // the component contraction needs: gain = omf * log-odds with omf > 0; bias >= 0 (csegment) so
+  // that intra-component records (> bias) are always visible and ahead of cross records (< bias);
+  // pysegmenter divides (gain + bias) by n1*n2, which only separates the two kinds when bias == 0
+  if (mode == MN_MODE_COMPONENTS &&
+      !(opts->object_merge_factor > 0.0f &&
+        (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
+                                              : opts->merge_logprob_bias == 0.0f)))
+    mode = MN_MODE_ROUNDS;
   ObjState S = obj_state(c);
 
   MN_HIP(hipMemsetAsync(c->cnt, 0, sizeof(Counters), st));
@@ -385,6 +442,15 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // ---------------- phase A ----------------
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS);
   if (rc != MN_OK) return rc;
+  if (mode == MN_MODE_COMPONENTS) {
+    rc = run_components(c, P, st, R0);
+    if (rc < 0) return rc;
+    if (rc == 1) {                 // not sign-separable: start over with the general rounds
+      mode = MN_MODE_ROUNDS;
+      rc = run_phase_a(c, P, st, true);
+      if (rc != MN_OK) return rc;
+    }
+  }
 
   // ---------------- phase B ----------------
   long long merges = 0;
@@ -405,12 +471,23 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                        (const int*)c->mate, c->cnt);
     rounds = 1;
   }
-  {
+  if (mode == MN_MODE_COMPONENTS) {
+    // the table already holds the records between components: straight to the list
+    HashTab T = c->T;
+    T.mask = (unsigned)(c->cc_cap - 1);
+    MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
+    MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)N * sizeof(u64), st));
+    MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
+                       T, cur, c->ball, c->gmax, c->cnt);
+    if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
+    R = c->h_cnt->n_records;
+  } else {
     const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
   }
-  if (mode == MN_MODE_ROUNDS) {
+  if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
     while (R > finish_limit && rounds < 5000) {
       MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
       MN_HIP(hipMemsetAsync(c->mate, 0xFF, (size_t)N * sizeof(int), st));
@@ -447,7 +524,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
   {
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
-    if (mode == MN_MODE_ROUNDS && R > 0 && !opts->no_handover_refresh)
+    if (mode != MN_MODE_EXACT && R > 0 && !opts->no_handover_refresh)
       hipLaunchKernelGGL(mn_rec_refresh, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R);
     if (R <= MN_FIN2_MAXR) {
       // record list resident in LDS (96 KiB dynamic); the (object -> record) map lives in `label`

@@ -28,7 +28,7 @@ LIB_PATH = os.path.join(_HERE, "libmergenet_hip.so")
 
 MN_VARIANT_CSEGMENT = 0
 MN_VARIANT_PYSEGMENTER = 1
-MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS = 0, 1, 2
+MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS, MN_MODE_COMPONENTS = 0, 1, 2, 3
 MN_ERR_NO_BACKGROUND = -10
 
 SegmenterOptions = namedtuple("SegmenterOptions",

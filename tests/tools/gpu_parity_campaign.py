@@ -13,6 +13,7 @@ H, W, C = (int(sys.argv[1]), int(sys.argv[2])) + (9,) if len(sys.argv) > 2 else 
 SEEDS = list(range(int(sys.argv[3]) if len(sys.argv) > 3 else 2000, (int(sys.argv[3]) if len(sys.argv) > 3 else 2000) + (int(sys.argv[4]) if len(sys.argv) > 4 else 16)))
 NOISE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.15
 VARIANT = sys.argv[6] if len(sys.argv) > 6 else "csegment"     # or "pysegmenter" (options 0, 1/O, 0)
+MODE = int(sys.argv[7]) if len(sys.argv) > 7 else 0            # 0 AUTO, 2 ROUNDS, 3 COMPONENTS
 
 
 def oracle_one(seed):
@@ -38,10 +39,10 @@ if __name__ == "__main__":
         for seed in SEEDS:
             s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE)
             if VARIANT == "pysegmenter":
-                o = seg.default_options(mode=seg.MN_MODE_ROUNDS, variant=seg.MN_VARIANT_PYSEGMENTER,
+                o = seg.default_options(mode=MODE, variant=seg.MN_VARIANT_PYSEGMENTER,
                                         object_merge_factor=1.0 / len(offs), merge_logprob_bias=0.0)
             else:
-                o = seg.default_options(mode=seg.MN_MODE_ROUNDS)
+                o = seg.default_options(mode=MODE)
             mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
             gpu[seed] = (mask, classes, st)
         while not pending.ready():
@@ -53,7 +54,7 @@ if __name__ == "__main__":
         mask, classes, st = gpu[seed]
         ok = labels.masks_equivalent(mask, classes, rmask, rcls)
         eq += int(ok)
-        print("seed %d: %s  instances gpu %d ref %d  certified %d  gpu %.1f ms  oracle %.0f s  rel.loglik diff %.1e"
-              % (seed, "EQUAL" if ok else "DIFFERENT", len(classes), len(rcls), st["certified"], st["ms_total"], dt,
+        print("seed %d: %s  mode_used %d  instances gpu %d ref %d  certified %d  gpu %.1f ms  oracle %.0f s  rel.loglik diff %.1e"
+              % (seed, "EQUAL" if ok else "DIFFERENT", st["mode_used"], len(classes), len(rcls), st["certified"], st["ms_total"], dt,
                  abs(st["total_logprob"] - rlp) / abs(rlp)), flush=True)
-    print("parity campaign %s %dx%d noise %.2f: %d/%d images identical to the sequential reference order" % (VARIANT, H, W, NOISE, eq, len(SEEDS)))
+    print("parity campaign %s mode %d %dx%d noise %.2f: %d/%d images identical to the sequential reference order" % (VARIANT, MODE, H, W, NOISE, eq, len(SEEDS)))

@@ -10,7 +10,7 @@ offs = synth.generate_offsets(40, 10)
 s = synth.synth_v1(H, W, 9, offs, 1000)
 m = seg.Merger(H, W, 9, len(offs))
 cp = torch.from_numpy(s.class_probs).cuda(); sp = torch.from_numpy(s.sameness_probs).cuda()
-o = seg.default_options(mode=seg.MN_MODE_ROUNDS, subrounds=sub, finish_limit=fin)
+o = seg.default_options(mode=int(sys.argv[5]) if len(sys.argv) > 5 else seg.MN_MODE_AUTO, subrounds=sub, finish_limit=fin)
 for it in range(2):
     mask, table, part, st = m.segment(cp, sp, offs, o, want_partition=True)
 torch.cuda.synchronize()
