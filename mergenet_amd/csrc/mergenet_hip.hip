@@ -264,6 +264,30 @@ static long long count_records(int W, int H, int offset_dim, const int* offs) {
 
 static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+struct FillList {
+  FillJobs j;
+  size_t largest = 0;
+  FillList() { j.count = 0; }
+  void add(void* p, size_t bytes, unsigned char byte) {
+    if (!bytes) return;
+    j.ptr[j.count] = p;
+    j.bytes[j.count] = bytes;
+    j.pattern[j.count] = 0x01010101u * byte;
+    j.count++;
+    if (bytes > largest) largest = bytes;
+  }
+  bool full() const { return j.count == MN_FILL_JOBS; }
+  void launch(hipStream_t st) {
+    if (!j.count) return;
+    unsigned blocks = grid_for(largest / 16 + 1, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mn_fill_many, dim3(blocks), dim3(256), 0, st, j);
+    j.count = 0;
+    largest = 0;
+  }
+};
+
 static ObjState obj_state(mn_context* c) {
   ObjState S;
   S.ocls = c->ocls; S.osize = c->osize; S.parent = c->parent; S.lpsum = c->lpsum;
@@ -299,10 +323,14 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
 }
 
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
-static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge) {
+static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge,
+                       FillList* fills = nullptr) {
   const int N = P.N;
-  MN_HIP(hipMemsetAsync(c->lpvalid, 0, N, st));
-  MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
+  FillList own;
+  if (!fills) fills = &own;
+  fills->add(c->lpvalid, N, 0);
+  fills->add(c->matched, N, 0);
+  fills->launch(st);
   hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
                      c->parent, c->mate);
   MN_HIP(hipEventRecord(c->ev[0], st));
@@ -356,45 +384,53 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
 // Component contraction (mn_kernels_cc.h).  Precondition: objects initialised, class pass done.
 // Returns 0 when the input is sign-separable (object state + table of records between components
 // ready), 1 when it is not (caller falls back), < 0 on error.
-static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, long long R0) {
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256), gx(8 * ((grid_for(N, 256) + 7) / 8));
-  // row stage on the (0, +1) offset if the list has it (generate_offsets always does), then the
-  // shortest offsets first: they connect almost everything
-  for (int k = 0; k < P.O; k++)
-    if (P.di[k] == 0 && P.dj[k] == 1) {
-      hipLaunchKernelGGL(mn_cc_rows, dim3(grid_for(N, 256)), b, 0, st, P, c->parent, k);
-      break;
-    }
+  // tile stage on the unit offsets (0, +1) and (+-1, 0) if the list has them (generate_offsets
+  // always does); the sweep then takes the shortest offsets first: they connect almost everything
+  int kh = -1, kv = -1, dv = 0;
+  for (int k = 0; k < P.O; k++) {
+    if (kh < 0 && P.di[k] == 0 && P.dj[k] == 1) kh = k;
+    if (kv < 0 && P.dj[k] == 0 && (P.di[k] == 1 || P.di[k] == -1)) { kv = k; dv = P.di[k]; }
+  }
+  hipLaunchKernelGGL(mn_cc_tiles, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
+                     dim3(1024), 0, st, P, c->parent, kh, kv, dv);
   int ksplit = P.O < 2 ? P.O : 2;
   hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
-  hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, c->parent);
-  if (ksplit < P.O) {
+  const bool two = ksplit < P.O;
+  hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
+                     two ? (i64*)nullptr : c->lp_acc, c->ball);
+  if (two) {
     hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, ksplit, P.O);
-    hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, c->parent);
+    hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
+                       c->lp_acc, c->ball);
   }
-  MN_HIP(hipMemsetAsync(c->osize, 0, (size_t)N * sizeof(int), st));
-  MN_HIP(hipMemsetAsync(c->lp_acc, 0, (size_t)N * P.C * sizeof(i64), st));
-  MN_HIP(hipMemsetAsync(c->scalars + 6, 0, sizeof(int), st));
-  size_t cap = next_pow2((size_t)R0 / 8 + 4096);      // records between components are few
-  if (cap > c->cap) cap = c->cap;
-  c->cc_cap = cap;
+  // the violation counter, the table and the best-record slots were cleared by the caller's fill
   HashTab T = c->T;
-  T.mask = (unsigned)(cap - 1);
-  MN_HIP(hipMemsetAsync(T.key, 0xFF, cap * sizeof(u64), st));
-  MN_HIP(hipMemsetAsync(T.S, 0, cap * sizeof(i64), st));
-  MN_HIP(hipMemsetAsync(T.touched, 0, cap, st));
+  T.mask = (unsigned)(c->cc_cap - 1);
   const unsigned waves = grid_for(N, MN_CC_CHUNK);
-  hipLaunchKernelGGL(mn_cc_sums, dim3(grid_for((size_t)waves * 64, 256)), b, 0, st, P, S,
-                     (const unsigned char*)c->cls0, c->lp_acc, c->scalars + 6);
-  hipLaunchKernelGGL(mn_cc_edges, gx, b, 0, st, P, S, T, c->scalars + 6);
+  hipLaunchKernelGGL(mn_cc_sums, dim3(grid_for((size_t)waves * 64, MN_CC_SUM_THREADS),
+                          (P.C + 1 + MN_CC_SUM_PLANES - 1) / MN_CC_SUM_PLANES),
+                     dim3(MN_CC_SUM_THREADS), 0, st, P, S, (const unsigned char*)c->cls0, c->lp_acc,
+                     c->scalars + 6);
+  hipLaunchKernelGGL(mn_cc_edges, dim3(8 * ((grid_for(N, MN_CC_EDGE_THREADS) + 7) / 8)),
+                     dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, c->scalars + 6);
+  // Nothing waits for the verdict here: the object state and the record list are built right
+  // away and the violation count travels to the host together with the record count.  If the
+  // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
+  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc);
+  hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
+                     T, c->LA, c->ball, c->gmax, c->cnt);
   MN_HIP(hipGetLastError());
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
-  if (c->h_scalars[6] != 0) return 1;
-  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc);
-  MN_HIP(hipGetLastError());
+  if (c->h_scalars[6] != 0) {
+    MN_HIP(hipMemsetAsync(c->cnt, 0, sizeof(Counters), st));
+    return 1;
+  }
   return 0;
 }
 
@@ -429,21 +465,33 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // that intra-component records (> bias) are always visible and ahead of cross records (< bias);
   // pysegmenter divides (gain + bias) by n1*n2, which only separates the two kinds when bias == 0
   if (mode == MN_MODE_COMPONENTS &&
-      !(opts->object_merge_factor > 0.0f &&
+      !(opts->object_merge_factor >= 1e-20f &&
         (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;
   ObjState S = obj_state(c);
 
-  MN_HIP(hipMemsetAsync(c->cnt, 0, sizeof(Counters), st));
-  MN_HIP(hipMemsetAsync(c->scalars, 0, 8 * sizeof(int), st));
-  MN_HIP(hipMemsetAsync(c->mapbuf, 0xFF, (size_t)N * sizeof(int), st));
+  FillList fills;
+  fills.add(c->cnt, sizeof(Counters), 0);
+  fills.add(c->scalars, 8 * sizeof(int), 0);
+  fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);
+  if (mode == MN_MODE_COMPONENTS) {
+    // everything the contraction and the compaction after it expect cleared, in the same launch
+    size_t cap = next_pow2((size_t)R0 / 8 + 4096);      // records between components are few
+    if (cap > c->cap) cap = c->cap;
+    c->cc_cap = cap;
+    fills.add(c->T.key, cap * sizeof(u64), 0xFF);
+    fills.add(c->T.S, cap * sizeof(i64), 0);
+    fills.add(c->T.touched, cap, 0);
+    fills.add(c->label, (size_t)N * sizeof(int), 0xFF);   // finisher's object -> record map
+    fills.add(c->gmax, 64 * sizeof(unsigned), 0);
+  }
 
   // ---------------- phase A ----------------
-  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS);
+  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
-    rc = run_components(c, P, st, R0);
+    rc = run_components(c, P, st);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
@@ -472,16 +520,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     rounds = 1;
   }
   if (mode == MN_MODE_COMPONENTS) {
-    // the table already holds the records between components: straight to the list
-    HashTab T = c->T;
-    T.mask = (unsigned)(c->cc_cap - 1);
-    MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
-    MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)N * sizeof(u64), st));
-    MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
-    hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
-                       T, cur, c->ball, c->gmax, c->cnt);
-    if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
-    R = c->h_cnt->n_records;
+    R = c->h_cnt->n_records;       // run_components already compacted the table into the list
   } else {
     const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
@@ -533,7 +572,8 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, MN_FIN2_MAXR * 12));
         c->fin_lds_ready = 1;
       }
-      MN_HIP(hipMemsetAsync(c->label, 0xFF, (size_t)N * sizeof(int), st));
+      if (mode != MN_MODE_COMPONENTS)   // (cleared by the first fill in components mode)
+        MN_HIP(hipMemsetAsync(c->label, 0xFF, (size_t)N * sizeof(int), st));
       hipLaunchKernelGGL(mn_finisher_lds, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S,
                          cur, R, c->label, c->fin_lists, c->cnt, max_steps);
     } else {

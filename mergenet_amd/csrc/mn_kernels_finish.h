@@ -239,7 +239,9 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
   int* listB = lists + MN_FIN2_MAXR;
   int* touched = lists + 2 * MN_FIN2_MAXR;
 
-  for (int i = tid; i < MN_FIN2_MAXR; i += MN_FIN2_THREADS) {
+  // the list never grows, so every scan stops at R rounded up to the block size
+  const int Rp = min(MN_FIN2_MAXR, (R + MN_FIN2_THREADS - 1) / MN_FIN2_THREADS * MN_FIN2_THREADS);
+  for (int i = tid; i < Rp; i += MN_FIN2_THREADS) {
     unsigned w = 0, u = DEAD, v = DEAD;
     if (i < R) {
       const u64 k = L.key[i];
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     //         case -- its lane publishes the index, otherwise the tie rule (lowest u, v) runs ----
     unsigned m = 0;
     int midx = 0, mcnt = 0;
-#pragma unroll 8
-    for (int i = tid; i < MN_FIN2_MAXR; i += MN_FIN2_THREADS) {
+#pragma unroll 4
+    for (int i = tid; i < Rp; i += MN_FIN2_THREADS) {
       const unsigned w = lw[i];
       mcnt = (w > m) ? 1 : (mcnt + ((w == m) ? 1 : 0));
       midx = (w > m) ? i : midx;
@@ -285,13 +287,13 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
       if (tid == 0) st_acc[6]++;
 #endif
       if (wm == gmax) {
-        for (int i = tid; i < MN_FIN2_MAXR; i += MN_FIN2_THREADS)
+        for (int i = tid; i < Rp; i += MN_FIN2_THREADS)
           if (lw[i] == gmax) atomicMin(&sh_tie, ((u64)lu[i] << 32) | (u64)lv[i]);
       }
       __syncthreads();
       const u64 want = sh_tie;
       if (wm == gmax) {
-        for (int i = tid; i < MN_FIN2_MAXR; i += MN_FIN2_THREADS)
+        for (int i = tid; i < Rp; i += MN_FIN2_THREADS)
           if (lw[i] == gmax && (((u64)lu[i] << 32) | (u64)lv[i]) == want) sh_widx = i;
       }
       __syncthreads();
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     const unsigned a = (unsigned)sh_a, b = (unsigned)sh_b;
     const int mcls = sh_do_merge - 1;
     // one LDS scan: which records touch the survivor, which the absorbed object
-    for (int i0 = 0; i0 < MN_FIN2_MAXR; i0 += MN_FIN2_THREADS) {
+    for (int i0 = 0; i0 < Rp; i0 += MN_FIN2_THREADS) {
       const int i = i0 + tid;
       const unsigned u = lu[i], v = lv[i];
       const bool isA = u == a || v == a;

@@ -165,15 +165,45 @@ __global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
     const int oc = S.ocls[ro];
     t_cls = (double)logf(mn_ld_class(P, oc, p));
     if (cls0[p] != oc) bad_cls++;
-    for (int k = 0; k < P.O; k++) {
-      const int rr = r + P.di[k], cc = c + P.dj[k];
-      if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
-      const int q = rr * P.W + cc;
-      const float v = mn_same_value(P, P.same[(size_t)k * P.N + p]);
-      const float ls = logf(v), ld = mn_log1m(v);
-      const float g = (ls - ld) * P.omf;
-      if (root[q] == ro) { t_same += (double)ls; if (!(g > 0.0f)) bad++; }
-      else               { t_diff += (double)ld; if (!(g < 0.0f)) bad++; }
+    // for omf >= 1e-20 the sign of the float gain (log v - log(1-v)) * omf is the sign of v - 0.5
+    // (the two logs of a float next to 0.5 are still 4 ulp apart and the product cannot underflow),
+    // so only the one log that enters the sums is evaluated
+    const bool by_value = P.omf >= 1e-20f;
+    constexpr int G = 10;                     // offsets whose loads are in flight together
+    for (int k0 = 0; k0 < P.O; k0 += G) {
+      float vv[G];
+      int rq[G];
+      bool in[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const int k = k0 + j;
+        in[j] = false;
+        vv[j] = 0.5f;
+        rq[j] = ro;
+        if (k < P.O) {
+          const int rr = r + P.di[k], cc = c + P.dj[k];
+          if (rr >= 0 && rr < P.H && cc >= 0 && cc < P.W) {
+            in[j] = true;
+            vv[j] = P.same[(size_t)k * P.N + p];
+            rq[j] = root[rr * P.W + cc];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if (!in[j]) continue;
+        const float v = mn_same_value(P, vv[j]);
+        const bool inside = rq[j] == ro;
+        const float lg = inside ? logf(v) : mn_log1m(v);
+        bool pos, neg;
+        if (by_value) { pos = v > 0.5f; neg = v < 0.5f; }
+        else {
+          const float g = (logf(v) - mn_log1m(v)) * P.omf;
+          pos = g > 0.0f; neg = g < 0.0f;
+        }
+        if (inside) { t_same += (double)lg; if (!pos) bad++; }
+        else        { t_diff += (double)lg; if (!neg) bad++; }
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
