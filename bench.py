@@ -9,14 +9,21 @@ One "step" = one pass of the hot path over one batch of synthetic input: every r
 1024x2048 Cityscapes-shape image (C=9 classes, O=10 log-spiral offsets, options 0/1/0.03 of
 egs/cityscape/local/segment.py:134-136) whose probability maps are already resident in HBM, and --
 for N > 1 -- the final int32 masks and class tables are all-gathered over RCCL (the only exchange
-step of the path; images are independent).  Weak scaling: per-GPU work is fixed.
+step of the path; images are independent).  Weak scaling: per-GPU work is fixed.  Each rank cycles
+through POOL different images (636 MB of maps, more than the 256 MiB Infinity Cache), so a step
+reads its maps from HBM and not from a cache warmed by the previous step.
 
 Rank 0 prints ONE JSON line.  `value` = pixels merged by all ranks / wall time of the K timed
-steps (max over ranks), in Mpixel/s.  `roofline` prices the affinity-scoring pass (class pass +
-edge pass) with HIP events taken on the launch stream inside the library: algorithmic bytes =
-4*(C+O) B/pixel.  `cpu_baseline` times the reference's own compiled
-segment.cc (oracle/_ref, kind "reference") or, if that is absent, our C++ restatement (kind
-"port") on one core over a bounded 256x512 sample of the same generator.
+steps (max over ranks), in Mpixel/s, in the library's default mode (AUTO: the component
+contraction when the maps are sign-separable, else the general rounds -- `mode_used` says which
+ran).  `roofline` prices the slowest streaming kernel of the timed path with HIP events taken on
+the launch stream inside the library (algorithmic bytes: 4 B per plane value, SURVEY.md section
+8d: C class planes or O sameness planes per pass); `passes` lists every streaming pass of the
+step the same way, and `scoring_pass_general_path` is the class pass + edge pass of the general
+rounds (the north-star kernel), measured live on the same images outside the timed region.
+`cpu_baseline` times the reference's own compiled segment.cc (oracle/_ref, kind "reference")
+or, if that is absent, our C++ restatement (kind "port") on one core over a bounded 256x512
+sample of the same generator.
 """
 
 from __future__ import annotations
@@ -34,6 +41,7 @@ if ROOT not in sys.path:
 H, W, C = 1024, 2048, 9
 OFFSETS_ARGS = (40, 10)
 OPTS = (0.0, 1.0, 0.03)
+POOL = 4                       # images per rank, cycled: 4 x 159 MB of maps > 256 MiB Infinity Cache
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -60,9 +68,11 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-path", action="store_true")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,15 +93,19 @@ def main():
     torch.cuda.set_device(dev)
 
     offs = synth.generate_offsets(*OFFSETS_ARGS)
-    img = synth.synth_v1(H, W, C, offs, 1000 + rank)
-    cp = torch.from_numpy(img.class_probs).to(dev)
-    sp = torch.from_numpy(img.sameness_probs).to(dev)
-    merger = seg.Merger(H, W, C, len(offs), device=local_rank)
+    O = len(offs)
+    seeds = [1000 + (rank + j) % 8 for j in range(POOL)]
+    pool = []
+    for sd in seeds:
+        img = synth.synth_v1(H, W, C, offs, sd)
+        pool.append((torch.from_numpy(img.class_probs).to(dev), torch.from_numpy(img.sameness_probs).to(dev)))
+    merger = seg.Merger(H, W, C, O, device=local_rank)
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
-                               merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_ROUNDS)
+                               merge_logprob_bias=OPTS[2], mode=args.mode)
     from mergenet_amd.distributed import gather_masks
 
-    def step():
+    def step(i):
+        cp, sp = pool[i % POOL]
         mask, table, _, st = merger.segment(cp, sp, offs, opts)
         gathered = gather_masks(mask, table, st["num_instances"]) if world > 1 else None
         return mask, table, st, gathered
@@ -101,53 +115,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    score_ms, class_ms, edge_ms, merge_ms, out_ms = [], [], [], [], []
+    for i in range(args.warmup):
+        step(i)
+    keys = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_merge",
+            "ms_output", "ms_total")
+    acc = {k: 0.0 for k in keys}
+    modes = set()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mask, table, st, gathered = step()
-        score_ms.append(st["ms_score"]); class_ms.append(st["ms_class_pass"])
-        edge_ms.append(st["ms_edge_pass"]); merge_ms.append(st["ms_merge"]); out_ms.append(st["ms_output"])
+    for i in range(args.steps):
+        mask, table, st, gathered = step(args.warmup + i)
+        for k in keys:
+            acc[k] += st[k]
+        modes.add(st["mode_used"])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    avg = {k: acc[k] / args.steps for k in keys}
 
-    # instance-id match of EVERY rank's image against the reference's own result for that image
-    # (golden vectors tests/golden/cseg_synth_1024x2048_*.npz, produced by the reference's
-    # segment.cc in 380-540 s per image); outside the timed region
+    # instance-id match of EVERY image of every rank's pool against the reference's own result for
+    # that image (golden vectors tests/golden/cseg_synth_1024x2048_*.npz, produced by the
+    # reference's segment.cc in 380-540 s per image); outside the timed region
     from mergenet_amd import labels as ck      # plain numpy label-map comparison
-    gname = "cseg_synth_1024x2048_cfg2.npz" if rank == 0 else "cseg_synth_1024x2048_s%d.npz" % (1000 + rank)
-    golden = os.path.join(ROOT, "tests", "golden", gname)
     checked, equal = 0, 0
-    if os.path.exists(golden):
+    for j, sd in enumerate(seeds):
+        gname = "cseg_synth_1024x2048_cfg2.npz" if sd == 1000 else "cseg_synth_1024x2048_s%d.npz" % sd
+        golden = os.path.join(ROOT, "tests", "golden", gname)
+        if not os.path.exists(golden):
+            continue
         z = np.load(golden)
-        got_cls = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
-        checked = 1
-        equal = int(ck.masks_equivalent(mask.cpu().numpy(), got_cls, z["mask"],
-                                        [int(c) for c in z["object_class"]]))
+        m_j, t_j, _, st_j = merger.segment(pool[j][0], pool[j][1], offs, opts)
+        got_cls = [int(c) for c in t_j.cpu().numpy()[: st_j["num_instances"]]]
+        checked += 1
+        equal += int(ck.masks_equivalent(m_j.cpu().numpy(), got_cls, z["mask"],
+                                         [int(c) for c in z["object_class"]]))
     if world > 1:
         t = torch.tensor([checked, equal], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         checked, equal = int(t[0].item()), int(t[1].item())
-    id_match = {"vs": "reference segment.cc (golden vectors, seeds 1000+rank)",
+    id_match = {"vs": "reference segment.cc (golden vectors, seeds 1000..1007)",
                 "images_checked": checked, "images_equal": equal, "equal": bool(checked and checked == equal)}
 
+    # the general path (rounds) on the same images, outside the timed region: its affinity-scoring
+    # pass (class pass + edge pass) is the kernel the north star names
+    general = None
+    if rank == 0 and not args.no_general_path:
+        ropts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
+                                    merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_ROUNDS)
+        g = {"ms_class_pass": 0.0, "ms_edge_pass": 0.0, "ms_total": 0.0}
+        merger.segment(pool[0][0], pool[0][1], offs, ropts)
+        for j in range(POOL):
+            _, _, _, st_r = merger.segment(pool[j][0], pool[j][1], offs, ropts)
+            for k in g:
+                g[k] += st_r[k] / POOL
+        general = g
+
     if rank == 0:
-        avg_score_ms = sum(score_ms) / len(score_ms)
-        algo_bytes = 4.0 * (C + len(offs)) * H * W
-        achieved = algo_bytes / (avg_score_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate passes, FETCH_SIZE x2 on gfx950): collected once per round, kept in profiles/
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_score_1024x2048.json")
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                traffic = json.load(fh).get("affinity_scoring_pass_hbm_bytes_per_launch")
+        plane_bytes = 4.0 * H * W
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_components_1024x2048.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh).get("hbm_bytes_per_launch", {})
+
+        def price(name, ms, planes, what):
+            gbs = planes * plane_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "reads": what, "algorithmic_bytes": planes * plane_bytes,
+                    "avg_launch_ms": round(ms, 5), "achieved": round(gbs, 2),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name)}
+
+        if avg["ms_cc_sums"] > 0:      # components mode: labelling, then one sweep per plane kind
+            passes = [price("mn_cc_tiles+mn_cc_hook+mn_cc_flatten", avg["ms_cc_label"], O, "O sameness planes"),
+                      price("mn_cc_class_sums", avg["ms_cc_sums"], C, "C class planes"),
+                      price("mn_cc_edges", avg["ms_cc_edges"], O, "O sameness planes")]
+        else:
+            passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
+                      price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]
+        single = [p for p in passes if "+" not in p["kernel"]]
+        dom = max(single, key=lambda p: p["avg_launch_ms"])
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                    "algorithmic_bytes": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "timing": "hipEvent pairs on the launch stream around the kernel, inside the "
+                              "timed steps (includes the ~5 us dispatch gap; rocprofv3 kernel-only "
+                              "durations are in profiles/r01_bench_kernel_stats.csv)",
+                    "why_this_kernel": "slowest single streaming kernel of the timed path"}
         out = {
             "metric": "merged Mpixels/sec at 1024x2048",
             "value": round(world * args.steps * H * W / elapsed / 1e6, 4),
@@ -162,28 +217,40 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: one 1024x2048 Cityscapes-shape class+offset map per "
-                                   "GPU (C=9, O=10 generate_offsets(40,10), opts 0/1/0.03, "
-                                   "variant csegment, synth-v1 seeds 1000+rank)",
-                       "images_per_step": world, "H": H, "W": W, "C": C, "O": len(offs),
+                                   "GPU and step (C=9, O=10 generate_offsets(40,10), opts 0/1/0.03, "
+                                   "variant csegment, synth-v1 seeds 1000..1007, %d images per rank "
+                                   "in rotation)" % POOL,
+                       "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
+                       "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
+                       "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
                        "exchange": "all_gather of int32 masks + class tables over RCCL" if world > 1
                                    else "none (single GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "affinity-scoring pass = mn_class_pass + mn_edge_pass_fast<10,true>",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes": algo_bytes, "avg_launch_ms": round(avg_score_ms, 5),
-                         "class_pass_ms": round(sum(class_ms) / len(class_ms), 5),
-                         "edge_pass_ms": round(sum(edge_ms) / len(edge_ms), 5),
-                         "timing": "hipEvent pairs on the launch stream around each kernel (includes "
-                                   "the ~5 us dispatch gap per kernel; rocprofv3 kernel-only "
-                                   "durations are in profiles/r01_bench_kernel_stats.csv)"},
-            "phases_ms": {"score": round(avg_score_ms, 4),
-                          "merge": round(sum(merge_ms) / len(merge_ms), 4),
-                          "output": round(sum(out_ms) / len(out_ms), 4)},
+            "roofline": roofline,
+            "passes": passes,
+            "phases_ms": {"score": round(avg["ms_class_pass"] + avg["ms_edge_pass"], 4),
+                          "merge": round(avg["ms_merge"], 4),
+                          "output": round(avg["ms_output"], 4),
+                          "device_total": round(avg["ms_total"], 4)},
             "merge_stats": {"rounds": st["rounds"], "finisher_steps": st["finisher_steps"],
                             "merges": st["merges"], "certified": st["certified"],
                             "instances": st["num_instances"]},
             "id_match": id_match,
         }
+        if general is not None:
+            sc_ms = general["ms_class_pass"] + general["ms_edge_pass"]
+            sc = (C + O) * plane_bytes / (sc_ms * 1e-3) / 1e9
+            sc_traffic = None
+            old = os.path.join(ROOT, "profiles", "r01_pmc_score_1024x2048.json")
+            if os.path.exists(old):
+                with open(old) as fh:
+                    sc_traffic = json.load(fh).get("affinity_scoring_pass_hbm_bytes_per_launch")
+            out["scoring_pass_general_path"] = {
+                "bound": "hbm", "kernel": "mn_class_pass + mn_edge_pass_fast<10,true> (mode rounds)",
+                "achieved": round(sc, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(sc / HBM_PEAK_GBS, 4), "traffic": sc_traffic,
+                "algorithmic_bytes": (C + O) * plane_bytes, "avg_launch_ms": round(sc_ms, 5),
+                "whole_image_ms_rounds_mode": round(general["ms_total"], 3),
+                "note": "measured live with the same HIP events, outside the timed steps"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -81,7 +81,7 @@ typedef struct mn_options {
 
 typedef struct mn_stats {
   int status;
-  int mode_used;               /* MN_MODE_EXACT or MN_MODE_ROUNDS */
+  int mode_used;               /* MN_MODE_EXACT, MN_MODE_ROUNDS or MN_MODE_COMPONENTS */
   int certified;               /* 1: result proven equal to the sequential reference partition
                                   (sign-separable input, see DESIGN.md "certificate")           */
   int num_instances;           /* labels 1..K written to the mask */
@@ -100,6 +100,11 @@ typedef struct mn_stats {
   float ms_merge;              /* phase B */
   float ms_output;             /* labels, mask, class table, certificate, log-likelihood */
   float ms_total;
+  /* components mode only (0 otherwise), HIP events on the launch stream: */
+  float ms_cc_label;           /* mn_cc_tiles + mn_cc_hook + mn_cc_flatten: reads the O sameness planes */
+  float ms_cc_sums;            /* mn_cc_sums: reads the C class planes                                  */
+  float ms_cc_edges;           /* mn_cc_edges: reads the O sameness planes                              */
+  float ms_reserved;
 } mn_stats;
 
 typedef struct mn_context mn_context;

@@ -65,7 +65,8 @@ struct mn_context {
   Counters* h_cnt;        // pinned host mirror
   int* h_scalars;         // pinned
   double* h_lp;           // pinned
-  hipEvent_t ev[6];
+  size_t cc_sum_lds;
+  hipEvent_t ev[10];   // 0-4 phases, 6-9 components-mode kernels
   ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
   int last_valid;
   // staging for the host-pointer entry points
@@ -163,7 +164,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cnt), sizeof(Counters)));
   MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 8 * sizeof(int)));
   MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_lp), 4 * sizeof(double)));
-  for (int i = 0; i < 6; i++) MN_HIP(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 10; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   return MN_OK;
 }
 
@@ -207,7 +208,7 @@ extern "C" void mn_destroy(mn_context* c) {
   if (c->h_cnt) (void)hipHostFree(c->h_cnt);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_lp) (void)hipHostFree(c->h_lp);
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 10; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   free(c);
 }
@@ -250,6 +251,23 @@ static void fill_params(ImgParams* P, const float* d_class, const float* d_same,
   if (P->omf > 0.0f) {
     const double need = (o->variant == MN_VARIANT_CSEGMENT ? -2.0 : -1.0) * (double)P->bias / (double)P->omf;
     P->vmin_first = (float)(1.0 / (1.0 + exp(-need)) - 1e-3);
+  }
+  // Components mode argues "a record inside a component scores > bias, one between components
+  // < bias".  In float32 that needs the quotient gain / (n1 + n2) to survive the addition of the
+  // bias (and gain / (n1 * n2) not to underflow): |gain| of every single edge must be at least
+  // tau = 2 N ulp(bias)  (resp. 1e-30 N^2), i.e. its sameness value outside (sep_lo, sep_hi).
+  P->sep_hi = nextafterf(0.5f, 1.0f);
+  P->sep_lo = nextafterf(0.5f, 0.0f);
+  if (P->omf > 0.0f && P->bias >= 0.0f) {
+    const double n = (double)P->N;
+    const double ulp = (double)nextafterf(P->bias, INFINITY) - (double)P->bias;
+    const double tau = fmax(2.0 * n * ulp, 1e-30 * n * n) / (double)P->omf;
+    const double hi = 1.0 / (1.0 + exp(-tau)), lo = 1.0 / (1.0 + exp(tau));
+    float fh = (float)hi, fl = (float)lo;
+    if ((double)fh < hi) fh = nextafterf(fh, 1.0f);
+    if ((double)fl > lo) fl = nextafterf(fl, 0.0f);
+    if (fh > P->sep_hi) P->sep_hi = fh;
+    if (fl < P->sep_lo) P->sep_lo = fl;
   }
 }
 
@@ -323,14 +341,22 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
 }
 
 // phase A prologue + class pass (+ first edge pass when `edge` is set)
+// `components`: only the fills -- components mode labels first and takes the class planes in its
+// own sweep (mn_cc_class_sums), which also sets every field mn_init_objects would
 static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool edge,
-                       FillList* fills = nullptr) {
+                       FillList* fills = nullptr, bool components = false) {
   const int N = P.N;
   FillList own;
   if (!fills) fills = &own;
   fills->add(c->lpvalid, N, 0);
   fills->add(c->matched, N, 0);
   fills->launch(st);
+  if (components) {
+    MN_HIP(hipEventRecord(c->ev[0], st));
+    MN_HIP(hipEventRecord(c->ev[1], st));
+    MN_HIP(hipEventRecord(c->ev[2], st));
+    return MN_OK;
+  }
   hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
                      c->parent, c->mate);
   MN_HIP(hipEventRecord(c->ev[0], st));
@@ -395,6 +421,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
     if (kh < 0 && P.di[k] == 0 && P.dj[k] == 1) kh = k;
     if (kv < 0 && P.dj[k] == 0 && (P.di[k] == 1 || P.di[k] == -1)) { kv = k; dv = P.di[k]; }
   }
+  MN_HIP(hipEventRecord(c->ev[6], st));
   hipLaunchKernelGGL(mn_cc_tiles, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
                      dim3(1024), 0, st, P, c->parent, kh, kv, dv);
   int ksplit = P.O < 2 ? P.O : 2;
@@ -410,13 +437,28 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
   // the violation counter, the table and the best-record slots were cleared by the caller's fill
   HashTab T = c->T;
   T.mask = (unsigned)(c->cc_cap - 1);
-  const unsigned waves = grid_for(N, MN_CC_CHUNK);
-  hipLaunchKernelGGL(mn_cc_sums, dim3(grid_for((size_t)waves * 64, MN_CC_SUM_THREADS),
-                          (P.C + 1 + MN_CC_SUM_PLANES - 1) / MN_CC_SUM_PLANES),
-                     dim3(MN_CC_SUM_THREADS), 0, st, P, S, (const unsigned char*)c->cls0, c->lp_acc,
-                     c->scalars + 6);
-  hipLaunchKernelGGL(mn_cc_edges, dim3(8 * ((grid_for(N, MN_CC_EDGE_THREADS) + 7) / 8)),
-                     dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, c->scalars + 6);
+  MN_HIP(hipEventRecord(c->ev[7], st));
+  {
+    const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
+    if (lds > c->cc_sum_lds) {
+      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->cc_sum_lds = lds;
+    }
+    const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
+    hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
+                       c->lp_acc);
+  }
+  MN_HIP(hipEventRecord(c->ev[8], st));
+  if (P.W % 4 == 0)
+    hipLaunchKernelGGL(mn_cc_edges4, dim3(grid_for((size_t)N / 4, MN_CC_EDGE_THREADS)),
+                       dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
+                       c->scalars + 6);
+  else
+    hipLaunchKernelGGL(mn_cc_edges, dim3(8 * ((grid_for(N, MN_CC_EDGE_THREADS) + 7) / 8)),
+                       dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
+                       c->scalars + 6);
+  MN_HIP(hipEventRecord(c->ev[9], st));
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
@@ -488,7 +530,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   }
 
   // ---------------- phase A ----------------
-  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills);
+  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
     rc = run_components(c, P, st);
@@ -606,10 +648,14 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                      (const int*)c->root, (const int*)c->label, d_mask, d_partition);
   // certificate + log-likelihood
   {
-    const int vb = (int)grid_for(N, 256);
-    hipLaunchKernelGGL(mn_verify_edges, dim3(vb), dim3(256), 0, st, P, S,
-                       (const unsigned char*)c->cls0,
-                       (const int*)c->root, c->partial, c->scalars);
+    const bool four = P.W % 4 == 0;              // 4 pixels of one row per lane
+    const int vb = (int)grid_for(four ? (size_t)N / 4 : (size_t)N, 256);
+    if (four)
+      hipLaunchKernelGGL(mn_verify_edges4, dim3(vb), dim3(256), 0, st, P, S,
+                         (const unsigned char*)c->cls0, (const int*)c->root, c->partial, c->scalars);
+    else
+      hipLaunchKernelGGL(mn_verify_edges, dim3(vb), dim3(256), 0, st, P, S,
+                         (const unsigned char*)c->cls0, (const int*)c->root, c->partial, c->scalars);
     hipLaunchKernelGGL(mn_verify_reduce, dim3(1), dim3(256), 0, st, vb, (const double*)c->partial,
                        P.omf, c->lp_out);
     if (R > 0)
@@ -651,6 +697,11 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
     (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+    if (mode == MN_MODE_COMPONENTS) {
+      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); stats->ms_cc_label = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_edges = ms;
+    }
   }
   g_last_status = rc;
   return rc;

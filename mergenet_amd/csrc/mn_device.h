@@ -23,6 +23,8 @@ struct ImgParams {
   int variant, clip;
   int banded;          // 1: XCD-banded tile order in the neighbour-reading kernels (mn_xcd_tile)
   float vmin_first;    // pixel-level edges with a raw sameness value below this cannot reach priority >= 0
+  float sep_hi, sep_lo; // components mode: an edge inside a component needs a sameness value >= sep_hi,
+                        // one between components <= sep_lo (0.5 widened by the float32 rounding margin)
   const float* cls;    // [C][N] class probabilities (borrowed)
   const float* same;   // [O][N] sameness probabilities (borrowed)
   int di[MN_MAX_OFFSETS];
@@ -73,7 +75,7 @@ __device__ __forceinline__ float mn_ld_class(const ImgParams& P, int c, int p) {
 // that every kernel sees the same value for the same edge.
 __device__ __forceinline__ i64 mn_edge_fixed(float v) {
   const float oml = logf(v) - mn_log1m(v);
-  return __double2ll_rn((double)oml * MN_FIX_ONE);
+  return __float2ll_rn(oml * (float)MN_FIX_ONE);   // float * 2^30 is exact: same value as in double
 }
 __device__ __forceinline__ float mn_fixed_to_float(i64 s) {
   return (float)((double)s * (1.0 / MN_FIX_ONE));

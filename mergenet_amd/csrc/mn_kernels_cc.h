@@ -3,8 +3,9 @@
 //
 // Claim (csegment variant, object_merge_factor > 0, merge_logprob_bias >= 0).  Let the pixel
 // graph be SIGN-SEPARABLE: the connected components of the edges with positive log-odds are such
-// that (a) no edge inside a component has log-odds <= 0, (b) no edge between components has
-// log-odds >= 0, (c) all pixels of a component share one arg-max class.  Then at every moment of
+// that (a) every edge inside a component has gain >= tau, (b) every edge between components has
+// gain <= -tau, (c) all pixels of a component share one arg-max class; tau > 0 is the float32
+// rounding margin of fill_params (2 N ulp(bias): the quotient below must not vanish in the sum).  Then at every moment of
 // the reference's run (utils/csegment/segment.cc:539-727) every record between two sub-objects of
 // one component scores  sum(log-odds)*omf / (n1+n2) + bias  >  bias  (class delta 0, segment.cc:
 // 107-150) and every record between sub-objects of different components scores < bias (negative
@@ -17,9 +18,9 @@
 //   mn_cc_hook     lock-free union-find over the implicit pixel graph (positive edges), root =
 //                  lowest pixel id of the component; unit offsets first, then the rest;
 //   mn_cc_flatten  parent[p] = root (and the roots' accumulators cleared);
-//   mn_cc_sums     condition (c), component sizes and class log-prob sums (running sums per
-//                  lane, block table in LDS, 64-bit fixed-point atomics: order-independent);
-//   mn_cc_edges    conditions (a), (b) on every edge, records between components summed into
+//   mn_cc_class_sums  the class pass: arg-max class of every pixel, component sizes and class
+//                  log-prob sums (block table in LDS, 64-bit fixed-point atomics);
+//   mn_cc_edges    conditions (a), (b), (c); records between components summed into
 //                  the hash table (per lane while the key repeats, then per block in LDS);
 //   mn_cc_finish   fixed-point sums -> float object state.
 // The second phase (records between components, where the bias lets a 1.6 M-pixel background
@@ -197,18 +198,18 @@ __global__ __launch_bounds__(256) void mn_cc_flatten(int N, int C, int* __restri
   }
 }
 
-// Component sizes and class log-prob sums.  A wave walks MN_CC_CHUNK consecutive pixels of one
-// plane (blockIdx.y); every lane keeps a running sum for "its" root and adds it to a per-block
-// table in LDS when some lane's root changes or the chunk ends.  The block then issues ONE global
-// atomic per root: a 1.6 M-pixel background is a hot word for every wave of the image, and one
-// word takes only ~88 atomics/us.
-#define MN_CC_CHUNK 512
-#define MN_CC_ITERS (MN_CC_CHUNK / 64)
+// Class pass of components mode: one sweep over the C class planes gives every pixel its arg-max
+// class (same rule as mn_class_pass: first maximum of logf) AND adds its class log-probs and its
+// count to the sums of its component.  4 consecutive pixels per lane (16-byte loads); a lane whose
+// four pixels share a root -- nearly all do -- issues one LDS atomic per class into the block's
+// table (root -> C+1 fixed-point sums); the block then issues ONE global atomic per root and class:
+// a 1.6 M-pixel background is a hot word for every wave of the image, and one word takes only ~88
+// atomics/us.  64-bit fixed-point sums (2^-32) are order-independent.
 #define MN_CC_SUM_THREADS 1024
-#define MN_CC_SUM_SLOTS 128
-#define MN_CC_SUM_PLANES 1
+#define MN_CC_SUM_SLOTS 64
 __device__ __forceinline__ int mn_lds_root_slot(int* s_root, int root) {
-  unsigned h = ((unsigned)root * 2654435761u) >> 25;             // 7 bits
+  unsigned h = ((unsigned)root * 2654435761u) >> 26;             // 6 bits
+#pragma unroll 1
   for (int t = 0; t < MN_CC_SUM_SLOTS; t++) {
     int cur = s_root[h];                       // plain read first: the slot is usually there already
     if (cur == root) return (int)h;
@@ -219,95 +220,95 @@ __device__ __forceinline__ int mn_lds_root_slot(int* s_root, int root) {
   return -1;
 }
 
-__global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(ImgParams P, ObjState S,
-                                                                const unsigned char* __restrict__ cls0,
-                                                                i64* __restrict__ lp_acc,
-                                                                int* __restrict__ violations) {
+__device__ __forceinline__ void mn_cc_add(const ImgParams& P, const ObjState& S, int* s_root,
+                                          u64* s_val, i64* __restrict__ lp_acc, int root, int c,
+                                          int slot, i64 x) {
+  if (slot >= 0) atomicAdd(&s_val[slot * (P.C + 1) + c], (u64)x);
+  else if (c == P.C) atomicAdd(&S.osize[root], (int)x);
+  else atomicAdd(reinterpret_cast<u64*>(&lp_acc[(size_t)c * P.N + root]), (u64)x);
+}
+
+__global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
+    ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
+  u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
   __shared__ int s_root[MN_CC_SUM_SLOTS];
-  __shared__ u64 s_val[MN_CC_SUM_PLANES][MN_CC_SUM_SLOTS];
-  const int lane = threadIdx.x & 63;
-  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long begin_ll = (long long)wave_global * MN_CC_CHUNK;
-  const int begin = begin_ll < P.N ? (int)begin_ll : P.N;        // idle waves still reach the barriers
-  if (threadIdx.x < MN_CC_SUM_SLOTS) {
-    s_root[threadIdx.x] = -1;
-    for (int j = 0; j < MN_CC_SUM_PLANES; j++) s_val[j][threadIdx.x] = 0;
+  const int nval = MN_CC_SUM_SLOTS * (P.C + 1);
+  for (int i = threadIdx.x; i < nval; i += MN_CC_SUM_THREADS) s_val[i] = 0;
+  if (threadIdx.x < MN_CC_SUM_SLOTS) s_root[threadIdx.x] = -1;
+  __syncthreads();
+  const int n4 = P.N >> 2;
+  const int i = blockIdx.x * MN_CC_SUM_THREADS + threadIdx.x;
+  if (i < n4) {
+    const int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
+    const bool same = r.x == r.y && r.x == r.z && r.x == r.w;
+    const int s0 = mn_lds_root_slot(s_root, r.x);
+    const int s1 = same ? s0 : mn_lds_root_slot(s_root, r.y);
+    const int s2 = same ? s0 : mn_lds_root_slot(s_root, r.z);
+    const int s3 = same ? s0 : mn_lds_root_slot(s_root, r.w);
+    float4 best;
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    for (int c = 0; c < P.C; c++) {
+      float4 v = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)i);
+      if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
+      float4 l;
+      l.x = logf(v.x); l.y = logf(v.y); l.z = logf(v.z); l.w = logf(v.w);
+      if (c == 0) {
+        best = l;
+      } else {
+        if (l.x > best.x) { best.x = l.x; b0 = c; }
+        if (l.y > best.y) { best.y = l.y; b1 = c; }
+        if (l.z > best.z) { best.z = l.z; b2 = c; }
+        if (l.w > best.w) { best.w = l.w; b3 = c; }
+      }
+      // float * 2^32 is exact, so each term is the double-precision product rounded to nearest
+      const i64 f0 = __float2ll_rn(l.x * 4294967296.0f), f1 = __float2ll_rn(l.y * 4294967296.0f);
+      const i64 f2 = __float2ll_rn(l.z * 4294967296.0f), f3 = __float2ll_rn(l.w * 4294967296.0f);
+      if (same) {
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (f0 + f1) + (f2 + f3));
+      } else {
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, f0);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, f1);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, f2);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, f3);
+      }
+    }
+    if (same) {
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
+    } else {
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, P.C, s1, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, P.C, s2, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, P.C, s3, 1);
+    }
+    uchar4 o;
+    o.x = (unsigned char)b0; o.y = (unsigned char)b1; o.z = (unsigned char)b2; o.w = (unsigned char)b3;
+    *reinterpret_cast<uchar4*>(S.ocls + 4 * (size_t)i) = o;
+    *reinterpret_cast<uchar4*>(cls0 + 4 * (size_t)i) = o;
   }
-  // roots of this lane's pixels and the iterations before which the wave must flush (some lane
-  // changes root there) are the same for every plane: computed once
-  int root[MN_CC_ITERS];
-  bool flush_before[MN_CC_ITERS];
-  int bad = 0;
-#pragma unroll
-  for (int i = 0; i < MN_CC_ITERS; i++) {
-    const int p = begin + i * 64 + lane;
-    root[i] = p < P.N ? S.parent[p] : -1;
-    if (blockIdx.y == 0 && p < P.N && cls0[p] != cls0[root[i]]) bad++;   // (c) one class per component
-  }
-#pragma unroll
-  for (int i = 0; i < MN_CC_ITERS; i++) {
-    const bool chg = i > 0 && root[i] >= 0 && root[i - 1] >= 0 && root[i] != root[i - 1];
-    flush_before[i] = __ballot(chg) != 0;
-    if (i > 0 && root[i] < 0) root[i] = root[i - 1];              // tail lanes keep their last root
+  // tail pixels when N is not a multiple of 4: straight to the global sums
+  const int tail0 = n4 << 2;
+  if (i < P.N - tail0) {
+    const int p = tail0 + i;
+    const int root = S.parent[p];
+    float best = 0.0f;
+    int b = 0;
+    for (int c = 0; c < P.C; c++) {
+      const float l = logf(mn_ld_class(P, c, p));
+      if (c == 0 || l > best) { best = l; b = c; }
+      mn_cc_add(P, S, s_root, s_val, lp_acc, root, c, -1, __float2ll_rn(l * 4294967296.0f));
+    }
+    mn_cc_add(P, S, s_root, s_val, lp_acc, root, P.C, -1, 1);
+    S.ocls[p] = (unsigned char)b;
+    cls0[p] = (unsigned char)b;
   }
   __syncthreads();
-  // blockIdx.y selects MN_CC_SUM_PLANES consecutive planes (plane -1 = pixel counts, planes
-  // 0..C-1 = class log-probs); their loads are all issued before the first one is used
-  const int c_first = (int)blockIdx.y * MN_CC_SUM_PLANES - 1;
-  float val[MN_CC_SUM_PLANES][MN_CC_ITERS];
-#pragma unroll
-  for (int j = 0; j < MN_CC_SUM_PLANES; j++) {
-    const int c = c_first + j;
-#pragma unroll
-    for (int i = 0; i < MN_CC_ITERS; i++) {
-      const int p = begin + i * 64 + lane;
-      val[j][i] = (c >= 0 && c < P.C && p < P.N) ? mn_ld_class(P, c, p) : 1.0f;
-    }
+  for (int j = threadIdx.x; j < nval; j += MN_CC_SUM_THREADS) {
+    const u64 v = s_val[j];
+    if (v == 0) continue;
+    const int slot = j / (P.C + 1), c = j - slot * (P.C + 1);
+    mn_cc_add(P, S, s_root, s_val, lp_acc, s_root[slot], c, -1, (i64)v);
   }
-#pragma unroll
-  for (int j = 0; j < MN_CC_SUM_PLANES; j++) {
-    const int c = c_first + j;
-    if (c >= P.C) break;                      // uniform
-    i64 acc = 0;
-    int cur = -1;
-#pragma unroll
-    for (int i = 0; i <= MN_CC_ITERS; i++) {
-      if (i == MN_CC_ITERS || flush_before[i]) {
-        // every lane adds its own partial sum to the block table: 64 LDS atomics on one address
-        // cost less than the dozen cross-lane permutes of a 64-bit wave reduction
-        if (cur >= 0) {
-          const int slot = mn_lds_root_slot(s_root, cur);
-          if (slot >= 0) atomicAdd(&s_val[j][slot], (u64)acc);
-          else if (c < 0) atomicAdd(&S.osize[cur], (int)acc);
-          else atomicAdd(reinterpret_cast<u64*>(&lp_acc[(size_t)c * P.N + cur]), (u64)acc);
-        }
-        acc = 0;
-        cur = -1;
-      }
-      if (i < MN_CC_ITERS && begin + i * 64 + lane < P.N) {
-        cur = root[i];
-        // float * 2^32 is exact, so this is the double-precision product rounded to nearest
-        acc += (c < 0) ? (i64)1 : __float2ll_rn(logf(val[j][i]) * 4294967296.0f);
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < MN_CC_SUM_SLOTS) {
-    const int r = s_root[threadIdx.x];
-    if (r >= 0) {
-#pragma unroll
-      for (int j = 0; j < MN_CC_SUM_PLANES; j++) {
-        const int c = c_first + j;
-        const u64 v = s_val[j][threadIdx.x];
-        if (c >= P.C || v == 0) continue;
-        if (c < 0) atomicAdd(&S.osize[r], (int)(i64)v);
-        else atomicAdd(reinterpret_cast<u64*>(&lp_acc[(size_t)c * P.N + r]), v);
-      }
-    }
-  }
-  if (blockIdx.y != 0) return;                // condition (c) is counted once, by the first block row
-  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
-  if (lane == 0 && bad) atomicAdd(violations, bad);
 }
 
 // insert with a bounded probe sequence: the table is sized for "few records between components";
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(ImgParams P, Obj
 // caller falls back) instead of spinning
 __device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key, i64 s) {
   unsigned slot = mn_hash(key) & T.mask;
+#pragma unroll 1
   for (int t = 0; t < 256; t++) {
     const u64 prev = atomicCAS(&T.key[slot], MN_EMPTY, key);
     if (prev == MN_EMPTY || prev == key) {
@@ -335,6 +337,7 @@ __device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key,
 __device__ __forceinline__ bool mn_cc_lds_add(u64* s_key, u64* s_sum, const HashTab& T, u64 key,
                                               i64 s) {
   unsigned h = (mn_hash(key) >> 7) & (MN_CC_EDGE_SLOTS - 1);
+#pragma unroll 1
   for (int t = 0; t < 32; t++) {
     u64 prev = s_key[h];                       // plain read first: the slot is usually there already
     if (prev == MN_EMPTY) prev = atomicCAS(&s_key[h], MN_EMPTY, key);
@@ -345,6 +348,7 @@ __device__ __forceinline__ bool mn_cc_lds_add(u64* s_key, u64* s_sum, const Hash
 }
 
 __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, ObjState S, HashTab T,
+                                                                  const unsigned char* __restrict__ cls0,
                                                                   int* __restrict__ violations) {
   __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
   __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, O
   const bool live = p < P.N;
   int bad = 0;
   const int root = live ? S.parent[p] : 0;
+  if (live && cls0[p] != cls0[root]) bad++;                          // (c) one class per component
   const int r = live ? p / P.W : 0, c0 = live ? p - r * P.W : 0;
   // a pixel next to a boundary sees the same neighbouring component through most of its offsets:
   // the lane sums its cross edges while the key stays the same and adds to the block table (LDS
@@ -384,18 +389,106 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, O
 #pragma unroll
     for (int j = 0; j < G; j++) {
       if (!in[j]) continue;
-      // sign of the gain omf * log-odds: the fixed-point log-odds of a float v has the sign of
-      // v - 0.5 (|log-odds| >= 2^-23 next to 0.5, i.e. 2^7 fixed-point units) and the host
-      // only takes this path for omf >= 1e-20, so the product cannot underflow to zero
+      // the gain omf * log-odds has the sign of v - 0.5 (the fixed-point log-odds of a float
+      // next to 0.5 are still 2^7 units); sep_hi / sep_lo widen 0.5 by the margin that keeps the
+      // float32 priority of a record strictly on its side of the bias (fill_params)
       const float x = mn_same_value(P, v[j]);
-      if (rq[j] == root) { if (!(x > 0.5f)) bad++; continue; }       // (a)
-      if (!(x < 0.5f)) bad++;                                        // (b)
+      if (rq[j] == root) { if (!(x >= P.sep_hi)) bad++; continue; }  // (a)
+      if (!(x <= P.sep_lo)) bad++;                                   // (b)
       const u64 key = mn_key(root, rq[j]);
       const i64 s = mn_edge_fixed(x);
       if (key == ckey) { csum += s; continue; }
       if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
       ckey = key;
       csum = s;
+    }
+  }
+  if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+  __syncthreads();
+  if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
+    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x])) bad++;
+  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
+}
+
+// The same sweep with 4 consecutive pixels of one row per lane (W % 4 == 0): the sameness values
+// come as one 16-byte load per offset, the four neighbour roots as one (unaligned) 16-byte load,
+// and a lane next to a boundary folds up to 40 cross edges into its running sum before it touches
+// the block table.
+struct __attribute__((packed, aligned(4))) mn_int4u { int x, y, z, w; };
+__device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) {
+  const mn_int4u t = *reinterpret_cast<const mn_int4u*>(p);
+  return make_int4(t.x, t.y, t.z, t.w);
+}
+
+__global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, ObjState S, HashTab T,
+                                                                   const unsigned char* __restrict__ cls0,
+                                                                   int* __restrict__ violations) {
+  __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
+  __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
+  if (threadIdx.x < MN_CC_EDGE_SLOTS) { s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; }
+  __syncthreads();
+  const int n4 = P.N >> 2;
+  const int i = blockIdx.x * MN_CC_EDGE_THREADS + threadIdx.x;
+  const bool live = i < n4;
+  const int p0 = live ? 4 * i : 0;
+  int bad = 0;
+  const int r = p0 / P.W, c0 = p0 - r * P.W;
+  int root0 = 0, root1 = 0, root2 = 0, root3 = 0;
+  if (live) {
+    const int4 rv = *reinterpret_cast<const int4*>(S.parent + p0);
+    root0 = rv.x; root1 = rv.y; root2 = rv.z; root3 = rv.w;
+    const uchar4 own = *reinterpret_cast<const uchar4*>(cls0 + p0);
+    bad += (own.x != cls0[root0]) + (own.y != cls0[root1]) +         // (c) one class per component
+           (own.z != cls0[root2]) + (own.w != cls0[root3]);
+  }
+  u64 ckey = MN_EMPTY;
+  i64 csum = 0;
+  constexpr int G = 5;                                  // offsets whose loads are in flight together
+  for (int k0 = 0; k0 < P.O; k0 += G) {
+    float4 v[G];
+    int4 rq[G];
+    int first[G];                                       // column of the first neighbour, or INT_MIN
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const int k = k0 + j;
+      first[j] = INT_MIN;
+      if (live && k < P.O) {
+        const int rr = r + P.di[k];
+        if (rr >= 0 && rr < P.H) {
+          first[j] = c0 + P.dj[k];
+          v[j] = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
+          const long long q0 = (long long)rr * P.W + first[j];
+          if (q0 >= 0 && q0 + 3 < P.N) {
+            rq[j] = mn_ld_int4_unaligned(S.parent + q0);
+          } else {                                      // first / last pixels of the image
+            rq[j].x = (q0 >= 0 && q0 < P.N) ? S.parent[q0] : 0;
+            rq[j].y = (q0 + 1 >= 0 && q0 + 1 < P.N) ? S.parent[q0 + 1] : 0;
+            rq[j].z = (q0 + 2 >= 0 && q0 + 2 < P.N) ? S.parent[q0 + 2] : 0;
+            rq[j].w = (q0 + 3 >= 0 && q0 + 3 < P.N) ? S.parent[q0 + 3] : 0;
+          }
+        }
+      }
+    }
+    auto edge = [&](int col, float raw, int q, int own) {
+      if (col < 0 || col >= P.W) return;
+      const float x = mn_same_value(P, raw);                         // margins: see mn_cc_edges
+      if (q == own) { if (!(x >= P.sep_hi)) bad++; return; }         // (a)
+      if (!(x <= P.sep_lo)) bad++;                                   // (b)
+      const u64 key = mn_key(own, q);
+      const i64 sx = mn_edge_fixed(x);
+      if (key == ckey) { csum += sx; return; }
+      if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+      ckey = key;
+      csum = sx;
+    };
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      if (first[j] == INT_MIN) continue;
+      edge(first[j], v[j].x, rq[j].x, root0);
+      edge(first[j] + 1, v[j].y, rq[j].y, root1);
+      edge(first[j] + 2, v[j].z, rq[j].z, root2);
+      edge(first[j] + 3, v[j].w, rq[j].w, root3);
     }
   }
   if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;

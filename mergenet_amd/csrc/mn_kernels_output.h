@@ -225,6 +225,99 @@ __global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
         ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 
+// The same sums with 4 consecutive pixels of one row per lane (W % 4 == 0): 16-byte loads of the
+// sameness values and of the neighbours' roots (unaligned), a quarter of the load instructions.
+struct __attribute__((packed, aligned(4))) mn_int4_unaligned { int x, y, z, w; };
+
+__global__ __launch_bounds__(256) void mn_verify_edges4(ImgParams P, ObjState S,
+                                                        const unsigned char* __restrict__ cls0,
+                                                        const int* __restrict__ root,
+                                                        double* __restrict__ partial,
+                                                        int* __restrict__ violations) {
+  __shared__ double sh[3][4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double t_cls = 0.0, t_same = 0.0, t_diff = 0.0;
+  int bad = 0, bad_cls = 0;
+  if (i < (P.N >> 2)) {
+    const int p0 = 4 * i;
+    const int r = p0 / P.W, c = p0 - r * P.W;
+    const int4 ro = *reinterpret_cast<const int4*>(root + p0);
+    const uchar4 own = *reinterpret_cast<const uchar4*>(cls0 + p0);
+    const int oc0 = S.ocls[ro.x], oc1 = S.ocls[ro.y], oc2 = S.ocls[ro.z], oc3 = S.ocls[ro.w];
+    t_cls = ((double)logf(mn_ld_class(P, oc0, p0)) + (double)logf(mn_ld_class(P, oc1, p0 + 1))) +
+            ((double)logf(mn_ld_class(P, oc2, p0 + 2)) + (double)logf(mn_ld_class(P, oc3, p0 + 3)));
+    bad_cls = (own.x != oc0) + (own.y != oc1) + (own.z != oc2) + (own.w != oc3);
+    const bool by_value = P.omf >= 1e-20f;       // see mn_verify_edges
+    auto edge = [&](int col, float raw, int q, int mine) {
+      if (col < 0 || col >= P.W) return;
+      const float v = mn_same_value(P, raw);
+      const bool inside = q == mine;
+      const float lg = inside ? logf(v) : mn_log1m(v);
+      bool pos, neg;
+      if (by_value) { pos = v > 0.5f; neg = v < 0.5f; }
+      else {
+        const float g = (logf(v) - mn_log1m(v)) * P.omf;
+        pos = g > 0.0f; neg = g < 0.0f;
+      }
+      if (inside) { t_same += (double)lg; if (!pos) bad++; }
+      else        { t_diff += (double)lg; if (!neg) bad++; }
+    };
+    constexpr int G = 5;                         // offsets whose loads are in flight together
+    for (int k0 = 0; k0 < P.O; k0 += G) {
+      float4 vv[G];
+      int4 rq[G];
+      int first[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const int k = k0 + j;
+        first[j] = INT_MIN;
+        if (k < P.O) {
+          const int rr = r + P.di[k];
+          if (rr >= 0 && rr < P.H) {
+            first[j] = c + P.dj[k];
+            vv[j] = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
+            const long long q0 = (long long)rr * P.W + first[j];
+            if (q0 >= 0 && q0 + 3 < P.N) {
+              const mn_int4_unaligned t = *reinterpret_cast<const mn_int4_unaligned*>(root + q0);
+              rq[j] = make_int4(t.x, t.y, t.z, t.w);
+            } else {
+              rq[j].x = (q0 >= 0 && q0 < P.N) ? root[q0] : 0;
+              rq[j].y = (q0 + 1 >= 0 && q0 + 1 < P.N) ? root[q0 + 1] : 0;
+              rq[j].z = (q0 + 2 >= 0 && q0 + 2 < P.N) ? root[q0 + 2] : 0;
+              rq[j].w = (q0 + 3 >= 0 && q0 + 3 < P.N) ? root[q0 + 3] : 0;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if (first[j] == INT_MIN) continue;
+        edge(first[j], vv[j].x, rq[j].x, ro.x);
+        edge(first[j] + 1, vv[j].y, rq[j].y, ro.y);
+        edge(first[j] + 2, vv[j].z, rq[j].z, ro.z);
+        edge(first[j] + 3, vv[j].w, rq[j].w, ro.w);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    t_cls += __shfl_xor(t_cls, off);
+    t_same += __shfl_xor(t_same, off);
+    t_diff += __shfl_xor(t_diff, off);
+    bad += __shfl_xor(bad, off);
+    bad_cls += __shfl_xor(bad_cls, off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wave] = t_cls; sh[1][wave] = t_same; sh[2][wave] = t_diff;
+    if (bad) atomicAdd(violations, bad);
+    if (bad_cls) atomicAdd(violations + 3, bad_cls);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(size_t)blockIdx.x * 3 + threadIdx.x] =
+        ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+
 __global__ __launch_bounds__(256) void mn_verify_reduce(int nblocks, const double* __restrict__ partial,
                                                         float omf, double* __restrict__ out) {
   __shared__ double sh[3][256];

@@ -55,7 +55,9 @@ class MnStats(ctypes.Structure):
                 ("merges", ctypes.c_longlong), ("total_logprob", ctypes.c_double),
                 ("ms_score", ctypes.c_float), ("ms_class_pass", ctypes.c_float),
                 ("ms_edge_pass", ctypes.c_float), ("ms_merge", ctypes.c_float),
-                ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float)]
+                ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
+                ("ms_cc_edges", ctypes.c_float), ("ms_reserved", ctypes.c_float)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

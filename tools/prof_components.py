@@ -1,0 +1,21 @@
+"""Whole merger in the default mode, repeated with cold caches (for rocprofv3 --pmc / --kernel-trace
+on the GPU box): python tools/prof_components.py [n]."""
+import sys
+sys.path.insert(0, '.')
+import torch
+from mergenet_amd import synth, segmenter as seg
+H, W = 1024, 2048
+offs = synth.generate_offsets(40, 10)
+s = synth.synth_v1(H, W, 9, offs, 1000)
+m = seg.Merger(H, W, 9, len(offs))
+cp = torch.from_numpy(s.class_probs).cuda(); sp = torch.from_numpy(s.sameness_probs).cuda()
+# a 1 GiB scratch write between launches evicts the 256 MiB Infinity Cache so each image reads HBM
+scratch = torch.empty(256 << 20, dtype=torch.float32, device='cuda')
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+tot = 0.0
+for it in range(n):
+    scratch.fill_(float(it))
+    torch.cuda.synchronize()
+    _, _, _, st = m.segment(cp, sp, offs, seg.default_options())
+    tot += st["ms_total"]
+print("mode_used %d, avg device time %.3f ms per image (cold caches)" % (st["mode_used"], tot / n))
