@@ -428,11 +428,11 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
   hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
   const bool two = ksplit < P.O;
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
-                     two ? (i64*)nullptr : c->lp_acc, c->ball);
+                     two ? (i64*)nullptr : c->lp_acc);
   if (two) {
     hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, ksplit, P.O);
     hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
-                       c->lp_acc, c->ball);
+                       c->lp_acc);
   }
   // the violation counter, the table and the best-record slots were cleared by the caller's fill
   HashTab T = c->T;
@@ -526,6 +526,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     fills.add(c->T.S, cap * sizeof(i64), 0);
     fills.add(c->T.touched, cap, 0);
     fills.add(c->label, (size_t)N * sizeof(int), 0xFF);   // finisher's object -> record map
+    // every best-record slot, not only the components': if more records are left than the
+    // finisher takes, the rounds go on from this list and look at all N slots
+    fills.add(c->ball, (size_t)N * sizeof(u64), 0);
     fills.add(c->gmax, 64 * sizeof(unsigned), 0);
   }
 

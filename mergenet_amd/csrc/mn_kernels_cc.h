@@ -178,12 +178,11 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, int* __restrict__
 }
 
 // `lp_acc` set (last flatten): component sizes and the class sums of the roots start from zero --
-// only the roots' slots of the C planes (and of the best-record array) are ever used, so they are
-// cleared here instead of by a memset of all (C + 1) * N words.
+// only the roots' slots of the C planes are ever used, so they are cleared here instead of by a
+// memset of all C * N words.
 __global__ __launch_bounds__(256) void mn_cc_flatten(int N, int C, int* __restrict__ parent,
                                                      int* __restrict__ osize,
-                                                     i64* __restrict__ lp_acc,
-                                                     u64* __restrict__ best) {
+                                                     i64* __restrict__ lp_acc) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
   int x = p;
@@ -191,10 +190,8 @@ __global__ __launch_bounds__(256) void mn_cc_flatten(int N, int C, int* __restri
   parent[p] = x;
   if (lp_acc) {
     osize[p] = 0;
-    if (x == p) {
-      best[p] = 0;                            // best-record slot, filled by mn_compact
+    if (x == p)
       for (int c = 0; c < C; c++) lp_acc[(size_t)c * N + p] = 0;
-    }
   }
 }
 

@@ -320,3 +320,131 @@ def test_abi_entry_regrows_its_cached_context(oracle):
                                              np.ascontiguousarray(g["sameness_probs"]),
                                              g["spec"]["C"], list(g["offsets"]), *g["spec"]["opts"])
         assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), name
+
+
+# ---- components mode (connected components over the positive edges, then the finisher) ----------
+
+def _segment(cp, sp, offs, mode, opts=(0.0, 1.0, 0.03), variant=seg.MN_VARIANT_CSEGMENT):
+    ctx = seg.HostContext(cp.shape[1], cp.shape[2], cp.shape[0], len(offs))
+    try:
+        o = seg.default_options(same_different_bias=opts[0], object_merge_factor=opts[1],
+                                merge_logprob_bias=opts[2], mode=mode, clip_inputs=1, variant=variant)
+        return ctx.segment(cp, sp, offs, o)
+    finally:
+        ctx.close()
+
+
+def _components_vs_oracle(oracle, H, W, C, seed, noise, opts=(0.0, 1.0, 0.03), python_variant=False):
+    offs = synth.generate_offsets(12, 6)
+    s = synth.synth_v1(H, W, C, offs, seed, noise=noise)
+    if python_variant:
+        ref = oracle.run_pysegmenter(s.class_probs, s.sameness_probs, C, offs, *opts)
+        variant = seg.MN_VARIANT_PYSEGMENTER
+    else:
+        ref = oracle.run_csegment(s.class_probs, s.sameness_probs, C, offs, *opts)
+        variant = seg.MN_VARIANT_CSEGMENT
+    mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, seg.MN_MODE_COMPONENTS,
+                                       opts, variant)
+    return ref, mask, classes, part, st
+
+
+@pytest.mark.parametrize("name", [n for n in BIG if "256x512" not in n])
+def test_components_mode_equals_reference_on_large_goldens(oracle, name):
+    """Every large golden (reference segment.cc output) in components mode, forced."""
+    g = gu.load(name)
+    mask, classes, part, st = _run(g, seg.MN_MODE_COMPONENTS)
+    assert st["mode_used"] == seg.MN_MODE_COMPONENTS, "separable synthetic maps must not fall back"
+    assert st["rounds"] == 0
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+    assert st["merges"] == g["spec"]["H"] * g["spec"]["W"] - st["num_objects"]
+
+
+def test_auto_mode_picks_components_for_large_images(oracle):
+    g = gu.load("cseg_synth_512x1024_s1000")
+    mask, classes, part, st = _run(g, seg.MN_MODE_AUTO)
+    assert st["mode_used"] == seg.MN_MODE_COMPONENTS
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+@pytest.mark.parametrize("shape", [(48, 96, 3), (61, 100, 4), (33, 67, 2), (40, 41, 5)])
+def test_components_mode_ragged_widths_match_oracle(oracle, shape):
+    """Widths that are / are not multiples of 4 and 64 (tile borders, 1-pixel-per-lane sweeps)."""
+    H, W, C = shape
+    ref, mask, classes, part, st = _components_vs_oracle(oracle, H, W, C, 77, 0.15)
+    assert st["mode_used"] == seg.MN_MODE_COMPONENTS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+    assert oracle.same_partition(part, ref.partition), st
+    assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+    assert st["merges"] == ref.stats["n_merges"]
+
+
+def test_components_mode_falls_back_when_not_separable(oracle):
+    """Noise 0.45 flips edge signs inside instances: the check must send the image to the rounds."""
+    ref, mask, classes, part, st = _components_vs_oracle(oracle, 96, 160, 4, 5, 0.45)
+    assert st["mode_used"] == seg.MN_MODE_ROUNDS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+
+
+def test_components_mode_needs_nonnegative_bias_and_positive_factor(oracle):
+    for opts in [(0.0, 1.0, -0.02), (0.0, -1.0, 0.03)]:
+        ref, mask, classes, part, st = _components_vs_oracle(oracle, 64, 96, 3, 9, 0.15, opts=opts)
+        assert st["mode_used"] == seg.MN_MODE_ROUNDS
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (opts, st)
+
+
+def test_components_mode_python_variant_only_with_bias_zero(oracle):
+    ref, mask, classes, part, st = _components_vs_oracle(oracle, 64, 96, 3, 11, 0.15, opts=(0.0, 1.0, 0.0),
+                                                         python_variant=True)
+    assert st["mode_used"] == seg.MN_MODE_COMPONENTS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+    # with the Python variant's own bias the two kinds of record are not separated by the bias
+    ref, mask, classes, part, st = _components_vs_oracle(oracle, 64, 96, 3, 11, 0.15, opts=(0.0, 1.0, 0.05),
+                                                         python_variant=True)
+    assert st["mode_used"] == seg.MN_MODE_ROUNDS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+
+
+def _checkerboard(H, W, C, offs, cell_px, seed):
+    rng = np.random.default_rng(seed)
+    cell = (np.arange(H)[:, None] // cell_px) * ((W + cell_px - 1) // cell_px) + (np.arange(W)[None, :] // cell_px)
+    cmap = rng.integers(0, C, size=cell.max() + 1)[cell]
+    cp = np.full((C, H, W), 0.05, np.float32)
+    for c in range(C):
+        cp[c][cmap == c] = 0.9
+    cp += rng.uniform(0, 0.01, size=cp.shape).astype(np.float32)
+    sp = np.zeros((len(offs), H, W), np.float32)
+    for k, (di, dj) in enumerate(offs):
+        other = np.full((H, W), -1)
+        r0, r1 = max(0, -di), min(H, H - di)
+        c0, c1 = max(0, -dj), min(W, W - dj)
+        other[r0:r1, c0:c1] = cell[r0 + di:r1 + di, c0 + dj:c1 + dj]
+        sp[k] = np.where(other == cell, 0.9, 0.1) + rng.uniform(-0.05, 0.05, size=(H, W))
+    return cp.astype(np.float32), sp.astype(np.float32)
+
+
+def test_components_mode_many_small_components_overflowing_tables(oracle):
+    """A checkerboard of 4x4 cells: ~250 components per 4096-pixel block overflow the 64-slot LDS
+    table of the class sweep and crowd the 256-slot one of the edge sweep, so their direct
+    global-atomic paths run; the result is still the oracle's."""
+    offs = synth.generate_offsets(6, 4)
+    cp, sp = _checkerboard(96, 128, 3, offs, 4, 3)
+    ref = oracle.run_csegment(cp, sp, 3, offs, 0.0, 1.0, 0.03)
+    mask, classes, part, st = _segment(cp, sp, offs, seg.MN_MODE_COMPONENTS)
+    assert st["mode_used"] == seg.MN_MODE_COMPONENTS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+    assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+
+
+def test_components_mode_values_inside_rounding_margin_fall_back(oracle):
+    """An edge whose sameness value sits within the float32 rounding margin of 0.5 fails the
+    separability check even though its sign is right (sep_hi / sep_lo in fill_params)."""
+    offs = synth.generate_offsets(6, 4)
+    s = synth.synth_v1(48, 64, 2, offs, 21, noise=0.1)
+    sp = s.sameness_probs.copy()
+    inside = np.argwhere(sp[1] > 0.6)
+    r, c = inside[len(inside) // 2]
+    sp[1, r, c] = np.float32(0.5) + np.float32(1e-7)        # positive log-odds of ~4e-7
+    ref = oracle.run_csegment(s.class_probs, sp, 2, offs, 0.0, 1.0, 0.03)
+    mask, classes, part, st = _segment(s.class_probs, sp, offs, seg.MN_MODE_COMPONENTS)
+    assert st["mode_used"] == seg.MN_MODE_ROUNDS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
