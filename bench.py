@@ -190,7 +190,7 @@ def main():
         if avg["ms_cc_sums"] > 0:      # components mode: labelling, then one sweep per plane kind
             passes = [price("mn_cc_tiles+mn_cc_hook+mn_cc_flatten", avg["ms_cc_label"], O, "O sameness planes"),
                       price("mn_cc_class_sums", avg["ms_cc_sums"], C, "C class planes"),
-                      price("mn_cc_edges", avg["ms_cc_edges"], O, "O sameness planes")]
+                      price("mn_cc_edges4", avg["ms_cc_edges"], O, "O sameness planes")]
         else:
             passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
                       price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]

@@ -519,7 +519,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);
   if (mode == MN_MODE_COMPONENTS) {
     // everything the contraction and the compaction after it expect cleared, in the same launch
-    size_t cap = next_pow2((size_t)R0 / 8 + 4096);      // records between components are few
+    // records between components are few; a table that turns out too small fails the bounded
+    // insert, which counts as "not separable" and sends the image to the rounds
+    size_t cap = next_pow2((size_t)N / 8 + 8192);
     if (cap > c->cap) cap = c->cap;
     c->cc_cap = cap;
     fills.add(c->T.key, cap * sizeof(u64), 0xFF);
