@@ -8,8 +8,9 @@
 One "step" = one pass of the hot path over one batch of synthetic input: every rank merges ONE
 1024x2048 Cityscapes-shape image (C=9 classes, O=10 log-spiral offsets, options 0/1/0.03 of
 egs/cityscape/local/segment.py:134-136) whose probability maps are already resident in HBM, and --
-for N > 1 -- the final int32 masks and class tables are all-gathered over RCCL (the only exchange
-step of the path; images are independent).  Weak scaling: per-GPU work is fixed.  Each rank cycles
+for N > 1 -- the final masks and class tables are all-gathered over RCCL (the only exchange step
+of the path; images are independent; int16 wire format, the gather of step i overlaps the merge
+of step i+1, all of them complete inside the timed region).  Weak scaling: per-GPU work is fixed.  Each rank cycles
 through POOL different images (636 MB of maps, more than the 256 MiB Infinity Cache), so a step
 reads its maps from HBM and not from a cache warmed by the previous step.
 
@@ -83,10 +84,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MN_BENCH_REHEARSAL=1 (development only): ranks share the GPUs that exist and talk over gloo,
+    # to rehearse the N>1 control flow on a one-GPU box; the real runs are one rank per GPU on RCCL
+    rehearsal = os.environ.get("MN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     dev = torch.device("cuda", local_rank)
@@ -102,15 +111,19 @@ def main():
     merger = seg.Merger(H, W, C, O, device=local_rank)
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode)
-    from mergenet_amd.distributed import gather_masks
+    from mergenet_amd.distributed import MaskExchange
+    # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
+    ex = MaskExchange(H, W, dev) if world > 1 else None
 
     def step(i):
         cp, sp = pool[i % POOL]
         mask, table, _, st = merger.segment(cp, sp, offs, opts)
-        gathered = gather_masks(mask, table, st["num_instances"]) if world > 1 else None
-        return mask, table, st, gathered
+        slot = ex.submit(mask, table, st["num_instances"]) if ex is not None else None
+        return mask, table, st, slot
 
     def fence():
+        if ex is not None:
+            ex.drain()                 # every all-gather issued so far has completed
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -135,6 +148,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     avg = {k: acc[k] / args.steps for k in keys}
+
+    # what the last exchange delivered: every rank's own slice must be its own mask and table
+    exchange_ok = None
+    if ex is not None:
+        masks_w, tabs_w, counts_w = ex.result(gathered)
+        k = st["num_instances"]
+        good = bool((masks_w[rank].to(torch.int32) == mask).all()) and int(counts_w[rank]) == k
+        good &= bool((tabs_w[rank, :k].to(torch.int32) == table[:k]).all())
+        good &= bool((counts_w > 0).all())
+        t = torch.tensor([int(good)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(t.item())
 
     # instance-id match of EVERY image of every rank's pool against the reference's own result for
     # that image (golden vectors tests/golden/cseg_synth_1024x2048_*.npz, produced by the
@@ -223,8 +248,9 @@ def main():
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
-                       "exchange": "all_gather of int32 masks + class tables over RCCL" if world > 1
-                                   else "none (single GPU)"},
+                       "exchange": ("one all_gather per step of int16 masks + class tables over RCCL, "
+                                    "overlapped with the next step's merge; delivered data checked: %s"
+                                    % exchange_ok) if world > 1 else "none (single GPU)"},
             "roofline": roofline,
             "passes": passes,
             "phases_ms": {"score": round(avg["ms_class_pass"] + avg["ms_edge_pass"], 4),

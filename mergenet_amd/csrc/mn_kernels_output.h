@@ -352,3 +352,29 @@ __global__ __launch_bounds__(256) void mn_verify_records(ImgParams P, ObjState S
   const float margin = 1e-6f + 1e-5f * fabsf(P.bias);
   if (!(f < -margin)) atomicAdd(violations + 4, 1);
 }
+
+// ---- wire format of the multi-GPU exchange ------------------------------------------------------
+// One int16 buffer per image: [n_pixels labels][count][max_instances classes, -1 padded].  Labels
+// are 0..K with K <= max_instances (4096), classes < 128: half the bytes of the int32 mask on the
+// xGMI links, and mask + class table travel in ONE all-gather.
+__global__ __launch_bounds__(256) void mn_pack_wire(int n_pixels, int max_instances, int num_instances,
+                                                    const int* __restrict__ mask,
+                                                    const int* __restrict__ table,
+                                                    short* __restrict__ wire) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = n_pixels >> 2;
+  if (i < n4) {
+    const int4 m = *reinterpret_cast<const int4*>(mask + 4 * (size_t)i);
+    short4 o;
+    o.x = (short)m.x; o.y = (short)m.y; o.z = (short)m.z; o.w = (short)m.w;
+    *reinterpret_cast<short4*>(wire + 4 * (size_t)i) = o;
+  }
+  if (i < n_pixels - (n4 << 2)) wire[(n4 << 2) + i] = (short)mask[(n4 << 2) + i];
+  if (i <= max_instances) {
+    short v;
+    if (i == 0) v = (short)num_instances;
+    else v = (i <= num_instances) ? (short)table[i - 1] : (short)-1;
+    wire[(size_t)n_pixels + i] = v;
+  }
+}
+

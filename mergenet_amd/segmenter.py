@@ -70,6 +70,7 @@ _lib_handle = None
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
            "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_sameness_targets_device", "mn_instance_scores_device",
+           "mn_pack_wire_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -133,6 +134,9 @@ def load_library() -> ctypes.CDLL:
     lib.mn_sameness_targets_device.restype = ctypes.c_int
     lib.mn_instance_scores_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mn_instance_scores_device.restype = ctypes.c_int
+    lib.mn_pack_wire_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_pack_wire_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
     lib.mn_status_string.restype = ctypes.c_char_p
@@ -491,3 +495,22 @@ class Merger:
         if rc != 0:
             raise MergeNetError(rc)
         return out[:num_instances]
+
+
+def pack_wire(mask, class_table, num_instances: int, wire, max_instances: int) -> None:
+    """Device tensors: int32 mask [H,W] + class table -> int16 wire buffer of the mask exchange
+    (``mn_pack_wire_device``; layout in ``mergenet_amd/distributed.py``).  Runs on the current
+    torch stream of the mask's device."""
+    import torch
+    lib = load_library()
+    n = mask.numel()
+    if (mask.dtype != torch.int32 or class_table.dtype != torch.int32 or wire.dtype != torch.int16
+            or not mask.is_contiguous() or wire.numel() < n + 1 + max_instances
+            or class_table.numel() < num_instances):
+        raise AssertionError("pack_wire: int32 mask/table, int16 wire of n + 1 + max_instances")
+    stream = torch.cuda.current_stream(mask.device).cuda_stream
+    rc = lib.mn_pack_wire_device(mask.data_ptr(), class_table.data_ptr(), int(num_instances), n,
+                                 int(max_instances), wire.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise MergeNetError(rc)
+
