@@ -448,3 +448,19 @@ def test_components_mode_values_inside_rounding_margin_fall_back(oracle):
     mask, classes, part, st = _segment(s.class_probs, sp, offs, seg.MN_MODE_COMPONENTS)
     assert st["mode_used"] == seg.MN_MODE_ROUNDS
     assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+
+
+def test_components_mode_record_table_overflow_falls_back(oracle):
+    """Every edge negative: each pixel is its own component and the ~N*O records between them do
+    not fit the small table of this mode; the bounded insert must report it (not spin) and the
+    image is redone by the rounds -- where nothing merges, as in the reference."""
+    H, W, C = 96, 128, 3
+    offs = synth.generate_offsets(6, 4)
+    rng = np.random.default_rng(8)
+    cp = rng.uniform(0.1, 0.9, size=(C, H, W)).astype(np.float32)
+    sp = rng.uniform(0.05, 0.3, size=(len(offs), H, W)).astype(np.float32)
+    ref = oracle.run_csegment(cp, sp, C, offs, 0.0, 1.0, 0.03)
+    mask, classes, part, st = _segment(cp, sp, offs, seg.MN_MODE_COMPONENTS)
+    assert st["mode_used"] == seg.MN_MODE_ROUNDS
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+    assert oracle.same_partition(part, ref.partition), st

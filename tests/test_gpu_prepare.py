@@ -118,3 +118,27 @@ def test_instance_scores_are_the_class_margin(oracle):
         want = lp[tb[k - 1]][sel].sum() - lp[0][sel].sum()
         assert abs(scores[k - 1] - want) <= 1e-4 * abs(want)
     m.close()
+
+
+def test_pack_wire_matches_layout():
+    """mn_pack_wire_device: int16 [labels | K | classes padded with -1] (MaskExchange wire format)."""
+    import torch
+    from mergenet_amd import distributed as mnd
+    from mergenet_amd import segmenter as seg
+    for (H, W, K) in [(6, 10, 3), (7, 9, 0), (64, 128, 40)]:       # n % 4 != 0 included
+        g = torch.Generator().manual_seed(H * W + K)
+        mask = torch.randint(0, K + 1, (H, W), generator=g, dtype=torch.int32).cuda()
+        table = torch.full((H * W,), -1, dtype=torch.int32)
+        table[:K] = torch.randint(1, 100, (K,), generator=g, dtype=torch.int32)
+        table = table.cuda()
+        n = H * W
+        wire = torch.full((n + 1 + mnd.MAX_INSTANCES,), 12345, dtype=torch.int16, device="cuda")
+        seg.pack_wire(mask, table, K, wire, mnd.MAX_INSTANCES)
+        torch.cuda.synchronize()
+        w = wire.cpu()
+        assert w[:n].tolist() == mask.cpu().reshape(-1).tolist()
+        assert int(w[n]) == K
+        assert w[n + 1: n + 1 + K].tolist() == table[:K].cpu().tolist()
+        assert bool((w[n + 1 + K:] == -1).all())
+    with pytest.raises(seg.MergeNetError):
+        seg.pack_wire(mask, table, mnd.MAX_INSTANCES + 1, wire, mnd.MAX_INSTANCES)
