@@ -631,8 +631,6 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   MN_HIP(hipEventRecord(c->ev[3], st));
 
   // ---------------- output ----------------
-  hipLaunchKernelGGL(mn_roots, dim3(grid_for(N, 256)), dim3(256), 0, st, N, (const int*)c->parent,
-                     c->root);
   const unsigned char* pruned = NULL;
   if (opts->variant == MN_VARIANT_PYSEGMENTER) {
     MN_HIP(hipMemsetAsync(c->bg_key, 0, sizeof(u64), st));
@@ -646,11 +644,11 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   hipLaunchKernelGGL(mn_rank_count, dim3(nblk), dim3(256), 0, st, N, S, pruned, c->block_count,
                      c->scalars + 2);
   hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 1);
-  MN_HIP(hipMemsetAsync(d_object_class, 0xFF, (size_t)N * sizeof(int), st));
   hipLaunchKernelGGL(mn_rank_assign, dim3(nblk), dim3(256), 0, st, N, S, pruned,
                      (const int*)c->block_count, c->label, d_object_class);
   hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                     (const int*)c->root, (const int*)c->label, d_mask, d_partition);
+                     (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
+                     c->root, d_mask, d_partition, d_object_class);
   // certificate + log-likelihood
   {
     const bool four = P.W % 4 == 0;              // 4 pixels of one row per lane

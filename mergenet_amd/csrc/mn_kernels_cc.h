@@ -245,29 +245,37 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     const int s3 = same ? s0 : mn_lds_root_slot(s_root, r.w);
     float4 best;
     int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    // the next plane's load is issued before this plane's values are used (one extra float4 of
+    // registers: the kernel stays at two 1024-thread blocks per CU, which matters more here than
+    // deeper staging -- three planes in flight at 85 VGPRs measured slower)
+    float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
     for (int c = 0; c < P.C; c++) {
-      float4 v = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)i);
-      if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
-      float4 l;
-      l.x = logf(v.x); l.y = logf(v.y); l.z = logf(v.z); l.w = logf(v.w);
-      if (c == 0) {
-        best = l;
-      } else {
-        if (l.x > best.x) { best.x = l.x; b0 = c; }
-        if (l.y > best.y) { best.y = l.y; b1 = c; }
-        if (l.z > best.z) { best.z = l.z; b2 = c; }
-        if (l.w > best.w) { best.w = l.w; b3 = c; }
-      }
-      // float * 2^32 is exact, so each term is the double-precision product rounded to nearest
-      const i64 f0 = __float2ll_rn(l.x * 4294967296.0f), f1 = __float2ll_rn(l.y * 4294967296.0f);
-      const i64 f2 = __float2ll_rn(l.z * 4294967296.0f), f3 = __float2ll_rn(l.w * 4294967296.0f);
-      if (same) {
-        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (f0 + f1) + (f2 + f3));
-      } else {
-        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, f0);
-        mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, f1);
-        mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, f2);
-        mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, f3);
+      {
+        float4 v = nxt;
+        if (c + 1 < P.C)
+          nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
+        if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
+        float4 l;
+        l.x = logf(v.x); l.y = logf(v.y); l.z = logf(v.z); l.w = logf(v.w);
+        if (c == 0) {
+          best = l;
+        } else {
+          if (l.x > best.x) { best.x = l.x; b0 = c; }
+          if (l.y > best.y) { best.y = l.y; b1 = c; }
+          if (l.z > best.z) { best.z = l.z; b2 = c; }
+          if (l.w > best.w) { best.w = l.w; b3 = c; }
+        }
+        // float * 2^32 is exact, so each term is the double-precision product rounded to nearest
+        const i64 f0 = __float2ll_rn(l.x * 4294967296.0f), f1 = __float2ll_rn(l.y * 4294967296.0f);
+        const i64 f2 = __float2ll_rn(l.z * 4294967296.0f), f3 = __float2ll_rn(l.w * 4294967296.0f);
+        if (same) {
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (f0 + f1) + (f2 + f3));
+        } else {
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, f0);
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, f1);
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, f2);
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, f3);
+        }
       }
     }
     if (same) {

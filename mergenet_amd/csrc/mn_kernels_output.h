@@ -13,15 +13,6 @@
 
 #define MN_SCAN_ITEMS 1024   /* pixels per block in the label ranking */
 
-__global__ __launch_bounds__(256) void mn_roots(int N, const int* __restrict__ parent,
-                                                int* __restrict__ root) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N) return;
-  int r = p;
-  while (parent[r] != r) r = parent[r];
-  root[p] = r;
-}
-
 // ---- Python-variant prune (segmenter.py:351-375) ----------------------------------------------
 // background = class-0 object with the most pixels (first such in ascending id);
 // every other object with lp[cls] - lp[0] < threshold is dumped into it (label 0).
@@ -131,15 +122,23 @@ __global__ __launch_bounds__(256) void mn_rank_assign(int N, ObjState S,
   }
 }
 
-__global__ __launch_bounds__(256) void mn_write_mask(int N, const int* __restrict__ root,
+// Last pass of the output: union forest -> root (kept for the certificate), mask[p] = label of the
+// root, optional partition, and the -1 padding of the class table from index K on
+// (segment.cc:497-509) -- K is read from the device, entries below K were written by mn_rank_assign.
+__global__ __launch_bounds__(256) void mn_write_mask(int N, const int* __restrict__ parent,
                                                      const int* __restrict__ label,
-                                                     int* __restrict__ mask,
-                                                     int* __restrict__ partition) {
+                                                     const int* __restrict__ num_instances,
+                                                     int* __restrict__ root, int* __restrict__ mask,
+                                                     int* __restrict__ partition,
+                                                     int* __restrict__ object_class) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
-  const int r = root[p];
+  int r = p;
+  while (parent[r] != r) r = parent[r];
+  root[p] = r;
   mask[p] = label[r];
   if (partition) partition[p] = r;
+  if (p >= *num_instances) object_class[p] = -1;
 }
 
 // ---- certificate + log-likelihood over the pixel graph ----------------------------------------
