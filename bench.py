@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 H, W, C = 1024, 2048, 9
 OFFSETS_ARGS = (40, 10)
 OPTS = (0.0, 1.0, 0.03)
+PIPELINED_DEPTH = 4            # images in flight in the `pipelined` side measurement
 POOL = 4                       # images per rank, cycled: 4 x 159 MB of maps > 256 MiB Infinity Cache
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
@@ -73,7 +74,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="images in flight per GPU (contexts + host threads + streams); 1 = serial")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,18 +112,71 @@ def main():
     for sd in seeds:
         img = synth.synth_v1(H, W, C, offs, sd)
         pool.append((torch.from_numpy(img.class_probs).to(dev), torch.from_numpy(img.sameness_probs).to(dev)))
-    merger = seg.Merger(H, W, C, O, device=local_rank)
+    # `--pipeline D` contexts, each driven by its own host thread on its own HIP stream: the merge
+    # of one image has two host round trips (record count, final statistics) during which the GPU
+    # would idle, and most of its kernels are latency-bound, so D images in flight fill the gaps
+    # (4 in flight: 1.8x the images per second).  Steps are handed out round-robin and collected in
+    # step order.  The default is 1: kernels of concurrent images share the chip, so their
+    # HIP-event durations -- and with them the roofline fractions -- would describe the
+    # contention, not the kernels; the pipelined rate is reported beside the line (`pipelined`).
+    depth = max(1, args.pipeline)
+    n_ctx = max(depth, PIPELINED_DEPTH if (world == 1 and not args.no_pipelined) else 1)
+    mergers = [seg.Merger(H, W, C, O, device=local_rank) for _ in range(n_ctx)]
+    merger = mergers[0]
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode)
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
     ex = MaskExchange(H, W, dev) if world > 1 else None
 
-    def step(i):
-        cp, sp = pool[i % POOL]
-        mask, table, _, st = merger.segment(cp, sp, offs, opts)
-        slot = ex.submit(mask, table, st["num_instances"]) if ex is not None else None
-        return mask, table, st, slot
+    import queue
+    import threading
+
+    def run_steps(first, count, depth=depth):
+        """Steps first .. first+count-1; returns the results of the last one and the sums."""
+        done = [queue.Queue() for _ in range(depth)]
+
+        def worker(w):
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(dev) if depth > 1 else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(stream):
+                for i in range(first + w, first + count, depth):
+                    cp, sp = pool[i % POOL]
+                    try:
+                        done[w].put(mergers[w].segment(cp, sp, offs, opts))
+                    except Exception as e:           # surfaces in the collecting thread
+                        done[w].put(e)
+                        return
+
+        threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(depth)]
+        if depth > 1:
+            for t in threads:
+                t.start()
+        last = None
+        sums = {k: 0.0 for k in KEYS}
+        modes = set()
+        for n in range(count):
+            if depth > 1:
+                res = done[n % depth].get()
+                if isinstance(res, Exception):
+                    raise res
+            else:
+                cp, sp = pool[(first + n) % POOL]
+                res = merger.segment(cp, sp, offs, opts)
+            mask, table, _, st = res
+            slot = None
+            if ex is not None:                 # exchanges are issued by ONE thread, in step order
+                mask.record_stream(torch.cuda.current_stream(dev))
+                table.record_stream(torch.cuda.current_stream(dev))
+                slot = ex.submit(mask, table, st["num_instances"])
+            for k in KEYS:
+                sums[k] += st[k]
+            modes.add(st["mode_used"])
+            last = (mask, table, st, slot)
+        for t in threads:
+            if depth > 1:
+                t.join()
+        return last, sums, modes
 
     def fence():
         if ex is not None:
@@ -128,21 +185,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    keys = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_merge",
+    KEYS = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_merge",
             "ms_output", "ms_total")
-    acc = {k: 0.0 for k in keys}
-    modes = set()
+    keys = KEYS
+    if args.warmup:
+        run_steps(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        mask, table, st, gathered = step(args.warmup + i)
-        for k in keys:
-            acc[k] += st[k]
-        modes.add(st["mode_used"])
+    (mask, table, st, gathered), acc, modes = run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+
+    # the same steps with PIPELINED_DEPTH images in flight (one GPU; outside the contract line)
+    pipelined = None
+    if world == 1 and not args.no_pipelined and depth == 1:
+        run_steps(0, 2 * PIPELINED_DEPTH, PIPELINED_DEPTH)
+        fence()
+        tp = time.perf_counter()
+        (pm, pt, pst, _), _, _ = run_steps(args.warmup, args.steps, PIPELINED_DEPTH)
+        fence()
+        dtp = time.perf_counter() - tp
+        pipelined = {"depth": PIPELINED_DEPTH, "value": round(args.steps * H * W / dtp / 1e6, 2),
+                     "unit": "Mpixel/s", "ms_per_step": round(dtp / args.steps * 1e3, 4),
+                     "last_mask_equals_serial_run": bool(torch.equal(pm, mask)),
+                     "how": "%d contexts, host threads and HIP streams, steps round-robin; same images, "
+                            "same checks; kernels of concurrent images share the chip, so per-kernel "
+                            "durations roughly double while images per second rise" % PIPELINED_DEPTH}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,6 +314,7 @@ def main():
                                    "variant csegment, synth-v1 seeds 1000..1007, %d images per rank "
                                    "in rotation)" % POOL,
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
+                       "pipeline_depth": depth,
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
                        "exchange": ("one all_gather per step of int16 masks + class tables over RCCL, "
@@ -262,6 +331,8 @@ def main():
                             "instances": st["num_instances"]},
             "id_match": id_match,
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if general is not None:
             sc_ms = general["ms_class_pass"] + general["ms_edge_pass"]
             sc = (C + O) * plane_bytes / (sc_ms * 1e-3) / 1e9
