@@ -168,7 +168,7 @@ def main():
             if ex is not None:                 # exchanges are issued by ONE thread, in step order
                 mask.record_stream(torch.cuda.current_stream(dev))
                 table.record_stream(torch.cuda.current_stream(dev))
-                slot = ex.submit(mask, table, st["num_instances"])
+                slot = ex.submit(mask, table, st["num_instances"], st["total_logprob"])
             for k in KEYS:
                 sums[k] += st[k]
             modes.add(st["mode_used"])
@@ -224,7 +224,7 @@ def main():
         k = st["num_instances"]
         good = bool((masks_w[rank].to(torch.int32) == mask).all()) and int(counts_w[rank]) == k
         good &= bool((tabs_w[rank, :k].to(torch.int32) == table[:k]).all())
-        good &= bool((counts_w > 0).all())
+        good &= bool((counts_w > 0).all()) and float(ex.logprobs(gathered)[rank]) == st["total_logprob"]
         t = torch.tensor([int(good)], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         exchange_ok = bool(t.item())

@@ -193,10 +193,12 @@ int mn_instance_scores_device(mn_context* ctx, float* d_scores, void* stream);
 
 /* Wire format of the multi-GPU mask exchange (the all-gather of final instance masks the north
  * star asks for; the reference has no exchange, its jobs write files: segment.py:59-61).  d_wire is
- * int16 [n_pixels + 1 + max_instances]: the labels (0..K), K, then the classes of labels 1..K
- * padded with -1.  Needs no context; max_instances <= 32767. */
+ * int16 [n_pixels + 1 + max_instances + 4]: the labels (0..K), K, the classes of labels 1..K
+ * padded with -1, then the float64 total log-likelihood as four 16-bit words, low word first
+ * (the scalars ride the same gather).  Needs no context; max_instances <= 32767. */
 int mn_pack_wire_device(const int* d_mask, const int* d_object_class, int num_instances,
-                        int n_pixels, int max_instances, short* d_wire, void* stream);
+                        double total_logprob, int n_pixels, int max_instances, short* d_wire,
+                        void* stream);
 
 int mn_last_status(void);
 const char* mn_status_string(int status);

@@ -916,9 +916,11 @@ extern "C" int mn_instance_scores_device(mn_context* c, float* d_scores, void* s
 }
 
 // Wire format of the mask exchange (mergenet_amd/distributed.py): d_wire is int16
-// [n_pixels + 1 + max_instances] = labels, instance count, classes padded with -1.
+// [n_pixels + 1 + max_instances + 4] = labels, instance count, classes padded with -1, and the
+// four 16-bit words (low first) of the float64 total log-likelihood.
 extern "C" int mn_pack_wire_device(const int* d_mask, const int* d_object_class, int num_instances,
-                                   int n_pixels, int max_instances, short* d_wire, void* stream) {
+                                   double total_logprob, int n_pixels, int max_instances,
+                                   short* d_wire, void* stream) {
   if (!d_mask || !d_object_class || !d_wire || n_pixels <= 0 || max_instances <= 0 ||
       max_instances > 32767 || num_instances < 0 || num_instances > max_instances) {
     g_last_status = MN_ERR_ARGUMENT;
@@ -927,8 +929,8 @@ extern "C" int mn_pack_wire_device(const int* d_mask, const int* d_object_class,
   const size_t threads = (size_t)(n_pixels >> 2) > (size_t)max_instances + 1 ? (size_t)(n_pixels >> 2)
                                                                               : (size_t)max_instances + 1;
   hipLaunchKernelGGL(mn_pack_wire, dim3(grid_for(threads < 4 ? 4 : threads, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), n_pixels, max_instances, num_instances, d_mask,
-                     d_object_class, d_wire);
+                     static_cast<hipStream_t>(stream), n_pixels, max_instances, num_instances,
+                     total_logprob, d_mask, d_object_class, d_wire);
   MN_HIP(hipGetLastError());
   g_last_status = MN_OK;
   return MN_OK;

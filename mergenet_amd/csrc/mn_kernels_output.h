@@ -353,10 +353,12 @@ __global__ __launch_bounds__(256) void mn_verify_records(ImgParams P, ObjState S
 }
 
 // ---- wire format of the multi-GPU exchange ------------------------------------------------------
-// One int16 buffer per image: [n_pixels labels][count][max_instances classes, -1 padded].  Labels
-// are 0..K with K <= max_instances (4096), classes < 128: half the bytes of the int32 mask on the
-// xGMI links, and mask + class table travel in ONE all-gather.
+// One int16 buffer per image: [n_pixels labels][count][max_instances classes, -1 padded][4 words =
+// the float64 total log-likelihood].  Labels are 0..K with K <= max_instances (4096), classes
+// < 128: half the bytes of the int32 mask on the xGMI links, and mask, class table and
+// log-likelihood travel in ONE all-gather.
 __global__ __launch_bounds__(256) void mn_pack_wire(int n_pixels, int max_instances, int num_instances,
+                                                    double total_logprob,
                                                     const int* __restrict__ mask,
                                                     const int* __restrict__ table,
                                                     short* __restrict__ wire) {
@@ -374,6 +376,10 @@ __global__ __launch_bounds__(256) void mn_pack_wire(int n_pixels, int max_instan
     if (i == 0) v = (short)num_instances;
     else v = (i <= num_instances) ? (short)table[i - 1] : (short)-1;
     wire[(size_t)n_pixels + i] = v;
+  }
+  if (i < 4) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(total_logprob);
+    wire[(size_t)n_pixels + 1 + max_instances + i] = (short)((bits >> (16 * i)) & 0xFFFFull);
   }
 }
 

@@ -54,7 +54,8 @@ class MaskExchange:
     The merger needs 0.4 ms per 1024x2048 image; an int32 mask is 8 MiB, so a blocking exchange of
     8 of them over xGMI would cost more than the merge.  Two things keep the links off the critical
     path: the wire format is one int16 buffer per image -- ``[H*W labels][K][MAX_INSTANCES classes,
-    -1 padded]`` (labels <= 4096, classes < 128), half the bytes and ONE collective instead of two
+    -1 padded][float64 log-likelihood as 4 words]`` (labels <= 4096, classes < 128), half the
+    bytes and ONE collective instead of two
     -- and the collective of step i runs on the backend's own stream while the kernels of step
     i+1 run on the compute stream (``async_op``); a buffer is reused only after its collective
     has been waited for.
@@ -63,6 +64,7 @@ class MaskExchange:
         slot = ex.submit(mask, class_table, K)      # returns at once
         ...                                          # next image
         masks, tables, counts = ex.result(slot)      # int16 [world,H,W], int16 [world,4096], [world]
+        logliks = ex.logprobs(slot)                  # float64 [world]
         ex.drain()
     """
 
@@ -71,7 +73,7 @@ class MaskExchange:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.H, self.W, self.n = height, width, height * width
-        self.words = self.n + 1 + MAX_INSTANCES
+        self.words = self.n + 1 + MAX_INSTANCES + 4
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.depth = depth
         self.send = [torch.empty(self.words, dtype=torch.int16, device=device) for _ in range(depth)]
@@ -80,24 +82,25 @@ class MaskExchange:
         self.work = [None] * depth
         self.count = 0
 
-    def _pack(self, mask, class_table, num_instances, wire):
+    def _pack(self, mask, class_table, num_instances, wire, total_logprob):
         torch = self.torch
         if mask.is_cuda:                      # HIP kernel of the library, on the current stream
             from . import segmenter
-            segmenter.pack_wire(mask, class_table, num_instances, wire, MAX_INSTANCES)
+            segmenter.pack_wire(mask, class_table, num_instances, wire, MAX_INSTANCES, total_logprob)
             return
         wire[: self.n] = mask.reshape(-1)     # CPU tensors: the gloo tests
         wire[self.n] = num_instances
-        wire[self.n + 1:] = -1
+        wire[self.n + 1: self.n + 1 + MAX_INSTANCES] = -1
         wire[self.n + 1: self.n + 1 + num_instances] = class_table[:num_instances]
+        wire[self.n + 1 + MAX_INSTANCES:] = torch.tensor([total_logprob], dtype=torch.float64).view(torch.int16)
 
-    def submit(self, mask, class_table, num_instances: int) -> int:
+    def submit(self, mask, class_table, num_instances: int, total_logprob: float = float("nan")) -> int:
         if num_instances > MAX_INSTANCES:
             raise ValueError("more than %d instances in one image" % MAX_INSTANCES)
         torch = self.torch
         slot = self.count % self.depth
         self.wait(slot)
-        self._pack(mask, class_table, num_instances, self.send[slot])
+        self._pack(mask, class_table, num_instances, self.send[slot], total_logprob)
         if self.world == 1:
             self.recv[slot].copy_(self.send[slot])
         else:
@@ -116,7 +119,14 @@ class MaskExchange:
     def result(self, slot: int):
         self.wait(slot)
         r = self.recv[slot].view(self.world, self.words)
-        return (r[:, : self.n].view(self.world, self.H, self.W), r[:, self.n + 1:], r[:, self.n])
+        return (r[:, : self.n].view(self.world, self.H, self.W),
+                r[:, self.n + 1: self.n + 1 + MAX_INSTANCES], r[:, self.n])
+
+    def logprobs(self, slot: int):
+        """Total log-likelihood of every rank's image (float64 [world])."""
+        self.wait(slot)
+        r = self.recv[slot].view(self.world, self.words)
+        return r[:, self.n + 1 + MAX_INSTANCES:].reshape(-1).clone().view(self.torch.float64)
 
     def drain(self) -> None:
         for slot in range(self.depth):

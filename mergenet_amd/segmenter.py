@@ -134,8 +134,8 @@ def load_library() -> ctypes.CDLL:
     lib.mn_sameness_targets_device.restype = ctypes.c_int
     lib.mn_instance_scores_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mn_instance_scores_device.restype = ctypes.c_int
-    lib.mn_pack_wire_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_pack_wire_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.mn_pack_wire_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
@@ -497,7 +497,8 @@ class Merger:
         return out[:num_instances]
 
 
-def pack_wire(mask, class_table, num_instances: int, wire, max_instances: int) -> None:
+def pack_wire(mask, class_table, num_instances: int, wire, max_instances: int,
+              total_logprob: float = float("nan")) -> None:
     """Device tensors: int32 mask [H,W] + class table -> int16 wire buffer of the mask exchange
     (``mn_pack_wire_device``; layout in ``mergenet_amd/distributed.py``).  Runs on the current
     torch stream of the mask's device."""
@@ -505,12 +506,13 @@ def pack_wire(mask, class_table, num_instances: int, wire, max_instances: int) -
     lib = load_library()
     n = mask.numel()
     if (mask.dtype != torch.int32 or class_table.dtype != torch.int32 or wire.dtype != torch.int16
-            or not mask.is_contiguous() or wire.numel() < n + 1 + max_instances
+            or not mask.is_contiguous() or wire.numel() < n + 1 + max_instances + 4
             or class_table.numel() < num_instances):
-        raise AssertionError("pack_wire: int32 mask/table, int16 wire of n + 1 + max_instances")
+        raise AssertionError("pack_wire: int32 mask/table, int16 wire of n + 1 + max_instances + 4")
     stream = torch.cuda.current_stream(mask.device).cuda_stream
-    rc = lib.mn_pack_wire_device(mask.data_ptr(), class_table.data_ptr(), int(num_instances), n,
-                                 int(max_instances), wire.data_ptr(), ctypes.c_void_p(stream))
+    rc = lib.mn_pack_wire_device(mask.data_ptr(), class_table.data_ptr(), int(num_instances),
+                                 float(total_logprob), n, int(max_instances), wire.data_ptr(),
+                                 ctypes.c_void_p(stream))
     if rc != 0:
         raise MergeNetError(rc)
 

@@ -78,8 +78,9 @@ def _exchange_worker(rank, world, port, out):
         k = 1 + (rank + step) % 3
         table = torch.full((H * W,), -1, dtype=torch.int32)
         table[:k] = torch.arange(k, dtype=torch.int32) + 3 * rank + step
-        slots.append(ex.submit(mask, table, k))
+        slots.append(ex.submit(mask, table, k, -1000.5 * (rank + 1) - step))
         masks, tabs, counts = ex.result(slots[-1])
+        ok &= ex.logprobs(slots[-1]).tolist() == [-1000.5 * (r + 1) - step for r in range(world)]
         ok &= masks.dtype == torch.int16 and masks.shape == (world, H, W)
         ok &= tabs.shape == (world, mnd.MAX_INSTANCES)
         for r in range(world):
@@ -108,8 +109,9 @@ def test_mask_exchange_single_process_and_limits():
     ex = mnd.MaskExchange(3, 4, torch.device("cpu"))
     mask = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     table = torch.tensor([5, 7, -1, -1], dtype=torch.int32)
-    slot = ex.submit(mask, table, 2)
+    slot = ex.submit(mask, table, 2, -3.25)
     masks, tabs, counts = ex.result(slot)
+    assert ex.logprobs(slot).tolist() == [-3.25]
     assert masks.shape == (1, 3, 4) and masks[0].tolist() == mask.tolist()
     assert tabs[0, :3].tolist() == [5, 7, -1] and int(counts[0]) == 2
     with pytest.raises(ValueError):

@@ -132,13 +132,14 @@ def test_pack_wire_matches_layout():
         table[:K] = torch.randint(1, 100, (K,), generator=g, dtype=torch.int32)
         table = table.cuda()
         n = H * W
-        wire = torch.full((n + 1 + mnd.MAX_INSTANCES,), 12345, dtype=torch.int16, device="cuda")
-        seg.pack_wire(mask, table, K, wire, mnd.MAX_INSTANCES)
+        wire = torch.full((n + 1 + mnd.MAX_INSTANCES + 4,), 12345, dtype=torch.int16, device="cuda")
+        seg.pack_wire(mask, table, K, wire, mnd.MAX_INSTANCES, -12345.6789)
         torch.cuda.synchronize()
         w = wire.cpu()
         assert w[:n].tolist() == mask.cpu().reshape(-1).tolist()
         assert int(w[n]) == K
         assert w[n + 1: n + 1 + K].tolist() == table[:K].cpu().tolist()
-        assert bool((w[n + 1 + K:] == -1).all())
+        assert bool((w[n + 1 + K: n + 1 + mnd.MAX_INSTANCES] == -1).all())
+        assert float(w[n + 1 + mnd.MAX_INSTANCES:].clone().view(torch.float64)[0]) == -12345.6789
     with pytest.raises(seg.MergeNetError):
         seg.pack_wire(mask, table, mnd.MAX_INSTANCES + 1, wire, mnd.MAX_INSTANCES)
