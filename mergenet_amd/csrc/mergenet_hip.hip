@@ -407,10 +407,11 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   return MN_OK;
 }
 
-// Component contraction (mn_kernels_cc.h).  Precondition: objects initialised, class pass done.
-// Returns 0 when the input is sign-separable (object state + table of records between components
-// ready), 1 when it is not (caller falls back), < 0 on error.
-static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
+// Component contraction (mn_kernels_cc.h).  With `wait`: returns 0 when the input is
+// sign-separable (object state + list of records between components ready, count in h_cnt), 1
+// when it is not (caller falls back), < 0 on error.  Without: everything is queued, 0 is returned
+// and the verdict is read by the caller at the end.
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256), gx(8 * ((grid_for(N, 256) + 7) / 8));
@@ -466,6 +467,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
   hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
                      T, c->LA, c->ball, c->gmax, c->cnt);
   MN_HIP(hipGetLastError());
+  if (!wait) return 0;             // speculative: the caller finds out at its final synchronisation
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
@@ -476,11 +478,20 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st) {
   return 0;
 }
 
-extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int class_dim,
-                                 const float* d_adj_pred, int offset_dim, int W, int H,
-                                 int num_classes, const int* offset_list, int* d_mask,
-                                 int* d_object_class, int* d_partition, const mn_options* opts,
-                                 void* stream, mn_stats* stats) {
+// Internal verdicts of a speculative attempt (never returned to the caller).
+#define MN_RETRY_ROUNDS 1001   /* not sign-separable: redo with the rounds            */
+#define MN_RETRY_WAIT 1002     /* more records than the finisher takes: redo, waiting for the count */
+
+// One attempt.  `speculate`: in components mode the host does not wait for the record count and
+// the separability verdict in the middle of the image; finisher and output are queued behind the
+// contraction and everything is read at the one synchronisation at the end.  Sign-separable maps
+// with few components -- the case the mode exists for -- are done then; otherwise a verdict above
+// is returned and mn_segment_device runs the attempt again on the ordinary path.
+static int segment_attempt(mn_context* c, const float* d_class_pred, int class_dim,
+                           const float* d_adj_pred, int offset_dim, int W, int H,
+                           int num_classes, const int* offset_list, int* d_mask,
+                           int* d_object_class, int* d_partition, const mn_options* opts,
+                           void* stream, mn_stats* stats, int force_mode, bool speculate) {
   mn_options defaults;
   if (!opts) { mn_default_options(&defaults); opts = &defaults; }
   int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
@@ -500,7 +511,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   if (subrounds > MN_MAX_SUBROUNDS) subrounds = MN_MAX_SUBROUNDS;
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
                                                    : (opts->band_permille < 0 ? 0.0f : 0.1f);
-  int mode = opts->mode;
+  int mode = force_mode > 0 ? force_mode : opts->mode;
   if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS && mode != MN_MODE_COMPONENTS)
     mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_COMPONENTS;
   // the component contraction needs: gain = omf * log-odds with omf > 0; bias >= 0 (csegment) so
@@ -537,8 +548,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // ---------------- phase A ----------------
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
+  speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
   if (mode == MN_MODE_COMPONENTS) {
-    rc = run_components(c, P, st);
+    rc = run_components(c, P, st, !speculate);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
@@ -567,14 +579,16 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     rounds = 1;
   }
   if (mode == MN_MODE_COMPONENTS) {
-    R = c->h_cnt->n_records;       // run_components already compacted the table into the list
+    // run_components already compacted the table into the list; speculating, the count is still
+    // on the device: launches below are sized for the most the finisher takes
+    R = speculate ? finish_limit : c->h_cnt->n_records;
   } else {
     const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
   }
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
-    while (R > finish_limit && rounds < 5000) {
+    while (!speculate && R > finish_limit && rounds < 5000) {
       MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
       MN_HIP(hipMemsetAsync(c->mate, 0xFF, (size_t)N * sizeof(int), st));
       MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records, any_selected, ...
@@ -610,7 +624,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
   {
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
-    if (mode != MN_MODE_EXACT && R > 0 && !opts->no_handover_refresh)
+    // (records that come straight from the component contraction were scored a moment ago)
+    if (mode != MN_MODE_EXACT && R > 0 && !opts->no_handover_refresh &&
+        !(mode == MN_MODE_COMPONENTS && rounds == 0))
       hipLaunchKernelGGL(mn_rec_refresh, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R);
     if (R <= MN_FIN2_MAXR) {
       // record list resident in LDS (96 KiB dynamic); the (object -> record) map lives in `label`
@@ -622,7 +638,9 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
       if (mode != MN_MODE_COMPONENTS)   // (cleared by the first fill in components mode)
         MN_HIP(hipMemsetAsync(c->label, 0xFF, (size_t)N * sizeof(int), st));
       hipLaunchKernelGGL(mn_finisher_lds, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S,
-                         cur, R, c->label, c->fin_lists, c->cnt, max_steps);
+                         cur, R, c->label, c->fin_lists, c->cnt, max_steps,
+                         speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr,
+                         (const int*)(c->scalars + 6), finish_limit);
     } else {
       hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
                          c->touched_list, c->cnt, max_steps);
@@ -663,7 +681,7 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                        P.omf, c->lp_out);
     if (R > 0)
       hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
-                         c->scalars);
+                         c->scalars, speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr);
   }
   MN_HIP(hipEventRecord(c->ev[4], st));
   MN_HIP(hipGetLastError());
@@ -674,6 +692,10 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_lp, c->lp_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
+  if (speculate) {
+    if (c->h_scalars[6] != 0) return MN_RETRY_ROUNDS;
+    if (c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
+  }
   merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
   rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
   if (stats) {
@@ -707,6 +729,21 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     }
   }
   g_last_status = rc;
+  return rc;
+}
+
+extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int class_dim,
+                                 const float* d_adj_pred, int offset_dim, int W, int H,
+                                 int num_classes, const int* offset_list, int* d_mask,
+                                 int* d_object_class, int* d_partition, const mn_options* opts,
+                                 void* stream, mn_stats* stats) {
+  int rc = segment_attempt(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
+                           offset_list, d_mask, d_object_class, d_partition, opts, stream, stats, 0,
+                           true);
+  if (rc == MN_RETRY_ROUNDS || rc == MN_RETRY_WAIT)
+    rc = segment_attempt(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
+                         offset_list, d_mask, d_object_class, d_partition, opts, stream, stats,
+                         rc == MN_RETRY_ROUNDS ? MN_MODE_ROUNDS : 0, false);
   return rc;
 }
 

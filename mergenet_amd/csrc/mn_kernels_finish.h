@@ -219,9 +219,18 @@ __device__ __forceinline__ unsigned mn_fin_word(float st) {
   return (st >= 0.0f) ? (((st == 0.0f) ? 0u : __float_as_uint(st)) + 1u) : 0u;
 }
 
+// `spec` set (components mode): the host has not seen the record count yet.  R is read from
+// spec[0]; if it exceeds spec_limit, or the separability check counted violations (spec[1][0] != 0),
+// the kernel does nothing and the host, which learns both at its one synchronisation, redoes the
+// image on the ordinary path.
 __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     ImgParams P, ObjState S, RecList L, int R, int* __restrict__ maprec, int* __restrict__ lists,
-    Counters* __restrict__ cnt, long long max_steps) {
+    Counters* __restrict__ cnt, long long max_steps, const int* __restrict__ spec_records,
+    const int* __restrict__ spec_violations, int spec_limit) {
+  if (spec_records) {
+    R = *spec_records;
+    if (R > spec_limit || *spec_violations != 0) return;          // uniform
+  }
   // One CU runs this loop, and what bounds a step is instruction issue (16 waves share 4 SIMDs),
   // so the per-record work of the two scans is kept to a couple of instructions: the queue is an
   // array of sortable words, the keys are two u32 arrays.

@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256) void mn_verify_reduce(int nblocks, const doubl
 // Quotient condition of the certificate: no record between two final objects may still be
 // mergeable (priority must be negative with a margin that covers float32 accumulation).
 __global__ __launch_bounds__(256) void mn_verify_records(ImgParams P, ObjState S, RecList L, int R,
-                                                         int* __restrict__ violations) {
+                                                         int* __restrict__ violations,
+                                                         const int* __restrict__ spec_records) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (spec_records) R = min(R, *spec_records);     // components mode: count known on the device only
   if (i >= R) return;
   const u64 key = L.key[i];
   if (key == MN_EMPTY) return;
