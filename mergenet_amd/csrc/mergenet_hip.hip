@@ -426,7 +426,12 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   hipLaunchKernelGGL(mn_cc_tiles, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
                      dim3(1024), 0, st, P, c->parent, kh, kv, dv);
   int ksplit = P.O < 2 ? P.O : 2;
-  hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
+  if (kh >= 0 && kv >= 0 && kh < 2 && kv < 2)
+    // the first two offsets are the unit ones: only the tile borders are left of them
+    hipLaunchKernelGGL(mn_cc_borders, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
+                       dim3(128), 0, st, P, c->parent, kh, kv, dv);
+  else
+    hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
   const bool two = ksplit < P.O;
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
                      two ? (i64*)nullptr : c->lp_acc);

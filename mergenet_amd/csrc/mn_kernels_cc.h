@@ -109,6 +109,56 @@ __global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, int* __restrict
   parent[p] = ((int)blockIdx.y * MN_CC_TILE_ROWS + (x >> 6)) * P.W + (int)blockIdx.x * 64 + (x & 63);
 }
 
+// Border stage: after mn_cc_tiles the only unit-offset edges still open are those that cross a
+// tile border, and the 16 (or 64) edges of one border segment almost always ask for the same
+// union.  One block per tile: wave 0 takes the 16 edges across the tile's right border, wave 1 the
+// 64 edges across its lower (dv = +1) or upper (dv = -1) border; one lane per distinct pair of
+// roots does the union.  ~4 K unions for a 1024x2048 image instead of a sweep over every pixel.
+__global__ __launch_bounds__(128) void mn_cc_borders(ImgParams P, int* __restrict__ parent, int kh,
+                                                     int kv, int dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (int)blockIdx.y * MN_CC_TILE_ROWS, c0 = (int)blockIdx.x * 64;
+  int p = -1, q = -1;
+  if (wave == 0) {                                   // right border: (r0 + lane, c0 + 63) -> next column
+    const int r = r0 + lane, c = c0 + 63;
+    if (lane < MN_CC_TILE_ROWS && r < P.H && c + 1 < P.W) {
+      p = r * P.W + c;
+      if (mn_same_value(P, P.same[(size_t)kh * P.N + p]) > 0.5f) q = p + 1;
+    }
+  } else {                                           // the border the vertical offset crosses
+    const int r = dv > 0 ? r0 + MN_CC_TILE_ROWS - 1 : r0, c = c0 + lane;
+    if (r < P.H && r + dv >= 0 && r + dv < P.H && c < P.W) {
+      p = r * P.W + c;
+      if (mn_same_value(P, P.same[(size_t)kv * P.N + p]) > 0.5f) q = p + dv * P.W;
+    }
+  }
+  int a = 0, b = 0;
+  bool want = false;
+  if (q >= 0) {
+    a = mn_cc_find(parent, p);
+    b = mn_cc_find(parent, q);
+    want = a != b;
+  }
+  u64 todo = __ballot(want);
+  const u64 key = mn_key(a, b);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const u64 k0v = ((u64)(unsigned)__shfl((int)(key >> 32), first) << 32) |
+                    (u64)(unsigned)__shfl((int)(key & 0xFFFFFFFFull), first);
+    const bool mine = want && key == k0v;
+    if (lane == first) {
+      while (a != b) {                                  // hook the larger root under the smaller
+        if (a < b) { const int x = a; a = b; b = x; }
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) break;
+        a = mn_cc_find(parent, old);
+        b = mn_cc_find(parent, b);
+      }
+    }
+    todo &= ~__ballot(mine);
+  }
+}
+
 // Offsets [k0, k1) only: the sweep runs first over the two unit offsets, which already connect
 // almost every component, is flattened, and then runs over the rest, whose edges then find equal
 // roots at once (no atomic).
