@@ -281,7 +281,7 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name)}
 
         if avg["ms_cc_sums"] > 0:      # components mode: labelling, then one sweep per plane kind
-            passes = [price("mn_cc_tiles+mn_cc_hook+mn_cc_flatten", avg["ms_cc_label"], O, "O sameness planes"),
+            passes = [price("mn_cc_tiles+mn_cc_borders+mn_cc_hook+mn_cc_flatten", avg["ms_cc_label"], O, "O sameness planes"),
                       price("mn_cc_class_sums", avg["ms_cc_sums"], C, "C class planes"),
                       price("mn_cc_edges4", avg["ms_cc_edges"], O, "O sameness planes")]
         else:
