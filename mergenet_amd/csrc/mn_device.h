@@ -120,6 +120,66 @@ __device__ __forceinline__ float mn_score(const ImgParams& P, const ObjState& S,
   return (num + P.bias) / den;
 }
 
+// The same priority, computed by a whole wave for one record (u, v, oml uniform over the wave).
+// Round trip 1: all six object fields at once.  Only if the classes differ, round trip 2: lane c
+// takes class c and requests BOTH sources of its log-prob (summed table and class plane) for both
+// objects before any is used; the first maximum is found with log2(C) shuffle steps.  The
+// sequential finisher so pays one or two global round trips per score instead of two to four.
+// The arithmetic per class, the first-maximum rule and (best - lu) - lv are those of mn_score:
+// the results are bit-identical.  `fields`, if given, receives {n_u, n_v, valid_u, valid_v}.
+__device__ __forceinline__ float mn_score_wave(const ImgParams& P, const ObjState& S, int u, int v,
+                                               float oml, int* merged_cls, bool* gain_pos,
+                                               int* fields = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int cu = S.ocls[u], cv = S.ocls[v];
+  const bool vu = S.lpvalid[u] != 0, vv = S.lpvalid[v] != 0;
+  const int nu = S.osize[u], nv = S.osize[v];
+  if (fields) { fields[0] = nu; fields[1] = nv; fields[2] = vu ? 1 : 0; fields[3] = vv ? 1 : 0; }
+  float cdl = 0.0f;
+  int mc = cu;
+  if (cu != cv) {                                     // uniform
+    float best = 0.0f, lu = 0.0f, lv = 0.0f;
+    bool have_best = false;
+    int width = 64;                                   // lanes that hold a class in a chunk
+    while (width > 1 && (width >> 1) >= P.C) width >>= 1;
+    for (int c0 = 0; c0 < P.C; c0 += 64) {
+      const int c = c0 + lane;
+      float a = 0.0f, b = 0.0f;
+      if (c < P.C) {
+        const float as = S.lpsum[(size_t)c * P.N + u], ap = mn_ld_class(P, c, u);
+        const float bs = S.lpsum[(size_t)c * P.N + v], bp = mn_ld_class(P, c, v);
+        a = vu ? as : logf(ap);
+        b = vv ? bs : logf(bp);
+      }
+      // first maximum over the classes of this chunk: highest j, lowest c among equals
+      float j = a + b;
+      int jc = c < P.C ? c : 0x7FFFFFFF;
+      bool ok = c < P.C;
+      for (int off = width >> 1; off > 0; off >>= 1) {
+        const float oj = __shfl_xor(j, off);
+        const int oc = __shfl_xor(jc, off);
+        const bool ook = __shfl_xor((int)ok, off) != 0;
+        const bool take = ook && (!ok || oj > j || (oj == j && oc < jc));
+        if (take) { j = oj; jc = oc; ok = true; }
+      }
+      j = __shfl(j, 0); jc = __shfl(jc, 0);           // lanes beyond `width` did not take part
+      if (!have_best || j > best) { best = j; mc = jc; have_best = true; }
+      if (cu >= c0 && cu < c0 + 64) lu = __shfl(a, cu - c0);
+      if (cv >= c0 && cv < c0 + 64) lv = __shfl(b, cv - c0);
+    }
+    cdl = (best - lu) - lv;
+  }
+  *merged_cls = mc;
+  const float num = oml * P.omf + cdl;
+  *gain_pos = num > 0.0f;
+  if (P.variant == MN_VARIANT_CSEGMENT) {
+    const float den = (float)(nu + nv);
+    return num / den + P.bias;
+  }
+  const float den = (float)nu * (float)nv;
+  return (num + P.bias) / den;
+}
+
 // (priority, partner) packed so that an unsigned max picks the highest priority and, among
 // equal priorities, the LOWEST partner id.  Only priorities >= 0 are packed.  Object ids are
 // below 2^28, which leaves bit 31 of the low word for a flag ("likelihood gain > 0") that both

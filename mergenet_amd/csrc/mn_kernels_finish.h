@@ -308,29 +308,34 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
       __syncthreads();
     }
     MN_STAMP(0);
-    if (tid == 0) {
+    if (wave == 0) {
+      // ---- 2. re-score the popped record: the whole first wave, one global round trip ----
       const int bi = sh_widx;
+      const int pu = (int)lu[bi], pv = (int)lv[bi];
+      int mc;
+      bool pos;
+      int fld[4];
+      const float f = mn_score_wave(P, S, pu, pv, mn_fixed_to_float(L.S[bi]), &mc, &pos, fld);
+      if (tid == 0) {
       sh_tie = MN_EMPTY;
       sh_cnt = 0;
       sh_do_merge = 0;
       sh_nA = 0; sh_nB = 0; sh_nt = 0;
-      // ---- 2. re-score the popped record ----
-      const int pu = (int)lu[bi], pv = (int)lv[bi];
-      int mc;
-      bool pos;
-      const float f = mn_score(P, S, pu, pv, mn_fixed_to_float(L.S[bi]), &mc, &pos);
       const unsigned fw = mn_fin_word(f);
       // stored == fresh  <=>  equal queue words (both >= 0); the Python variant merges on >=
       const bool go = (P.variant == MN_VARIANT_CSEGMENT) ? (fw == gmax) : (fw >= gmax);
       if (!go) {
         lw[bi] = fw;
       } else {
-        int a = pu, bb = pv;
-        if (S.osize[a] < S.osize[bb]) { a = pv; bb = pu; }
-        sh_a = a; sh_b = bb;
-        sh_valid = (S.lpvalid[a] ? 1 : 0) | (S.lpvalid[bb] ? 2 : 0);
+        // survivor = larger object, tie keeps the lower id (pu); sizes and validity flags are
+        // the ones the score just read
+        const bool swap = fld[0] < fld[1];
+        sh_a = swap ? pv : pu;
+        sh_b = swap ? pu : pv;
+        sh_valid = swap ? ((fld[3] ? 1 : 0) | (fld[2] ? 2 : 0)) : ((fld[2] ? 1 : 0) | (fld[3] ? 2 : 0));
         sh_do_merge = 1 + mc;
         lw[bi] = 0; lu[bi] = DEAD; lv[bi] = DEAD;
+      }
       }
     }
     __syncthreads();
@@ -399,11 +404,22 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
       maprec[lu[i] == a ? lv[i] : lu[i]] = -1;
     }
     const int nt = sh_nt;
-    for (int j = tid; j < nt; j += MN_FIN2_THREADS) {
-      const int t = touched[j];
-      int mc;
-      bool pos;
-      lw[t] = mn_fin_word(mn_score(P, S, (int)lu[t], (int)lv[t], mn_fixed_to_float(L.S[t]), &mc, &pos));
+    if (nt <= 4 * MN_FIN2_WAVES) {
+      // few records to re-score: a wave each (one round trip per record instead of three)
+      for (int j = wave; j < nt; j += MN_FIN2_WAVES) {
+        const int t = touched[j];
+        int mc;
+        bool pos;
+        const float f = mn_score_wave(P, S, (int)lu[t], (int)lv[t], mn_fixed_to_float(L.S[t]), &mc, &pos);
+        if (lane == 0) lw[t] = mn_fin_word(f);
+      }
+    } else {
+      for (int j = tid; j < nt; j += MN_FIN2_THREADS) {
+        const int t = touched[j];
+        int mc;
+        bool pos;
+        lw[t] = mn_fin_word(mn_score(P, S, (int)lu[t], (int)lv[t], mn_fixed_to_float(L.S[t]), &mc, &pos));
+      }
     }
     merges++;
     __syncthreads();

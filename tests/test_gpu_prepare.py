@@ -143,3 +143,24 @@ def test_pack_wire_matches_layout():
         assert float(w[n + 1 + mnd.MAX_INSTANCES:].clone().view(torch.float64)[0]) == -12345.6789
     with pytest.raises(seg.MergeNetError):
         seg.pack_wire(mask, table, mnd.MAX_INSTANCES + 1, wire, mnd.MAX_INSTANCES)
+
+
+def test_mask_exchange_single_gpu_uses_the_pack_kernel():
+    """MaskExchange on device tensors without a process group: wire packed by the HIP kernel,
+    results come back as int16 views of the receive buffer."""
+    import torch
+    from mergenet_amd import distributed as mnd
+    H, W, K = 33, 47, 5
+    g = torch.Generator().manual_seed(7)
+    mask = torch.randint(0, K + 1, (H, W), generator=g, dtype=torch.int32).cuda()
+    table = torch.full((H * W,), -1, dtype=torch.int32)
+    table[:K] = torch.tensor([3, 1, 4, 1, 5], dtype=torch.int32)
+    table = table.cuda()
+    ex = mnd.MaskExchange(H, W, torch.device("cuda", 0))
+    slots = [ex.submit(mask, table, K, -77.125) for _ in range(3)]     # reuses both buffers
+    masks, tabs, counts = ex.result(slots[-1])
+    torch.cuda.synchronize()
+    assert masks.shape == (1, H, W) and bool((masks[0].to(torch.int32) == mask).all())
+    assert tabs[0, :K].tolist() == [3, 1, 4, 1, 5] and bool((tabs[0, K:] == -1).all())
+    assert int(counts[0]) == K and ex.logprobs(slots[-1]).tolist() == [-77.125]
+    ex.drain()
