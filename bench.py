@@ -108,74 +108,59 @@ def main():
     offs = synth.generate_offsets(*OFFSETS_ARGS)
     O = len(offs)
     seeds = [1000 + (rank + j) % 8 for j in range(POOL)]
-    pool = []
+    pool_images = []
     for sd in seeds:
         img = synth.synth_v1(H, W, C, offs, sd)
-        pool.append((torch.from_numpy(img.class_probs).to(dev), torch.from_numpy(img.sameness_probs).to(dev)))
-    # `--pipeline D` contexts, each driven by its own host thread on its own HIP stream: the merge
-    # of one image has two host round trips (record count, final statistics) during which the GPU
-    # would idle, and most of its kernels are latency-bound, so D images in flight fill the gaps
-    # (4 in flight: 1.8x the images per second).  Steps are handed out round-robin and collected in
-    # step order.  The default is 1: kernels of concurrent images share the chip, so their
+        pool_images.append((torch.from_numpy(img.class_probs).to(dev), torch.from_numpy(img.sameness_probs).to(dev)))
+    # `--pipeline D`: a mergenet_amd.segmenter.MergerPool of D contexts, each driven by its own
+    # host thread on its own HIP stream: the merge of one image has a host round trip during which
+    # the GPU would idle, and most of its kernels are latency-bound, so D images in flight fill
+    # the gaps (4 in flight: 1.8x the images per second).  Results are collected in step order.
+    # The default is 1: kernels of concurrent images share the chip, so their
     # HIP-event durations -- and with them the roofline fractions -- would describe the
     # contention, not the kernels; the pipelined rate is reported beside the line (`pipelined`).
     depth = max(1, args.pipeline)
-    n_ctx = max(depth, PIPELINED_DEPTH if (world == 1 and not args.no_pipelined) else 1)
-    mergers = [seg.Merger(H, W, C, O, device=local_rank) for _ in range(n_ctx)]
-    merger = mergers[0]
+    merger = seg.Merger(H, W, C, O, device=local_rank)
+    main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode)
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
     ex = MaskExchange(H, W, dev) if world > 1 else None
 
-    import queue
-    import threading
+    from collections import deque
 
-    def run_steps(first, count, depth=depth):
-        """Steps first .. first+count-1; returns the results of the last one and the sums."""
-        done = [queue.Queue() for _ in range(depth)]
-
-        def worker(w):
-            torch.cuda.set_device(dev)
-            stream = torch.cuda.Stream(dev) if depth > 1 else torch.cuda.current_stream(dev)
-            with torch.cuda.stream(stream):
-                for i in range(first + w, first + count, depth):
-                    cp, sp = pool[i % POOL]
-                    try:
-                        done[w].put(mergers[w].segment(cp, sp, offs, opts))
-                    except Exception as e:           # surfaces in the collecting thread
-                        done[w].put(e)
-                        return
-
-        threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(depth)]
-        if depth > 1:
-            for t in threads:
-                t.start()
+    def run_steps(first, count, pool=None):
+        """Steps first .. first+count-1, serially on `merger` or through a MergerPool (a window of
+        images in flight, results collected in step order); returns the last result and the sums."""
         last = None
         sums = {k: 0.0 for k in KEYS}
         modes = set()
-        for n in range(count):
-            if depth > 1:
-                res = done[n % depth].get()
-                if isinstance(res, Exception):
-                    raise res
-            else:
-                cp, sp = pool[(first + n) % POOL]
-                res = merger.segment(cp, sp, offs, opts)
+
+        def collect(res):
+            nonlocal last
             mask, table, _, st = res
             slot = None
             if ex is not None:                 # exchanges are issued by ONE thread, in step order
-                mask.record_stream(torch.cuda.current_stream(dev))
-                table.record_stream(torch.cuda.current_stream(dev))
                 slot = ex.submit(mask, table, st["num_instances"], st["total_logprob"])
             for k in KEYS:
                 sums[k] += st[k]
             modes.add(st["mode_used"])
             last = (mask, table, st, slot)
-        for t in threads:
-            if depth > 1:
-                t.join()
+
+        if pool is None:
+            for i in range(first, first + count):
+                cp, sp = pool_images[i % POOL]
+                collect(merger.segment(cp, sp, offs, opts))
+        else:
+            window = deque()
+            for i in range(first, first + count):
+                cp, sp = pool_images[i % POOL]
+                window.append(pool.submit(cp, sp, offs, opts))
+                if len(window) >= 4 * len(pool.mergers):
+                    collect(window.popleft().result())
+            while window:
+                collect(window.popleft().result())
         return last, sums, modes
 
     def fence():
@@ -189,27 +174,29 @@ def main():
             "ms_output", "ms_total")
     keys = KEYS
     if args.warmup:
-        run_steps(0, args.warmup)
+        run_steps(0, args.warmup, main_pool)
     fence()
     t0 = time.perf_counter()
-    (mask, table, st, gathered), acc, modes = run_steps(args.warmup, args.steps)
+    (mask, table, st, gathered), acc, modes = run_steps(args.warmup, args.steps, main_pool)
     fence()
     elapsed = time.perf_counter() - t0
 
     # the same steps with PIPELINED_DEPTH images in flight (one GPU; outside the contract line)
     pipelined = None
     if world == 1 and not args.no_pipelined and depth == 1:
-        run_steps(0, 2 * PIPELINED_DEPTH, PIPELINED_DEPTH)
+        side_pool = seg.MergerPool(H, W, C, O, depth=PIPELINED_DEPTH, device=local_rank)
+        run_steps(0, 2 * PIPELINED_DEPTH, side_pool)
         fence()
         tp = time.perf_counter()
-        (pm, pt, pst, _), _, _ = run_steps(args.warmup, args.steps, PIPELINED_DEPTH)
+        (pm, pt, pst, _), _, _ = run_steps(args.warmup, args.steps, side_pool)
         fence()
         dtp = time.perf_counter() - tp
+        side_pool.close()
         pipelined = {"depth": PIPELINED_DEPTH, "value": round(args.steps * H * W / dtp / 1e6, 2),
                      "unit": "Mpixel/s", "ms_per_step": round(dtp / args.steps * 1e3, 4),
                      "last_mask_equals_serial_run": bool(torch.equal(pm, mask)),
-                     "how": "%d contexts, host threads and HIP streams, steps round-robin; same images, "
-                            "same checks; kernels of concurrent images share the chip, so per-kernel "
+                     "how": "mergenet_amd.segmenter.MergerPool: %d contexts, host threads and HIP streams; "
+                            "same images; kernels of concurrent images share the chip, so per-kernel "
                             "durations roughly double while images per second rise" % PIPELINED_DEPTH}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -240,7 +227,7 @@ def main():
         if not os.path.exists(golden):
             continue
         z = np.load(golden)
-        m_j, t_j, _, st_j = merger.segment(pool[j][0], pool[j][1], offs, opts)
+        m_j, t_j, _, st_j = merger.segment(pool_images[j][0], pool_images[j][1], offs, opts)
         got_cls = [int(c) for c in t_j.cpu().numpy()[: st_j["num_instances"]]]
         checked += 1
         equal += int(ck.masks_equivalent(m_j.cpu().numpy(), got_cls, z["mask"],
@@ -259,9 +246,9 @@ def main():
         ropts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                     merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_ROUNDS)
         g = {"ms_class_pass": 0.0, "ms_edge_pass": 0.0, "ms_total": 0.0}
-        merger.segment(pool[0][0], pool[0][1], offs, ropts)
+        merger.segment(pool_images[0][0], pool_images[0][1], offs, ropts)
         for j in range(POOL):
-            _, _, _, st_r = merger.segment(pool[j][0], pool[j][1], offs, ropts)
+            _, _, _, st_r = merger.segment(pool_images[j][0], pool_images[j][1], offs, ropts)
             for k in g:
                 g[k] += st_r[k] / POOL
         general = g

@@ -164,3 +164,33 @@ def test_mask_exchange_single_gpu_uses_the_pack_kernel():
     assert tabs[0, :K].tolist() == [3, 1, 4, 1, 5] and bool((tabs[0, K:] == -1).all())
     assert int(counts[0]) == K and ex.logprobs(slots[-1]).tolist() == [-77.125]
     ex.drain()
+
+
+def test_merger_pool_equals_serial_merger_and_keeps_order():
+    """Four contexts / streams / host threads: every result equals the single-context result of
+    the same image, in submission order; inputs produced on the caller's stream just before."""
+    import torch
+    from mergenet_amd import segmenter as seg, synth
+    offs = synth.generate_offsets(12, 6)
+    H, W, C = 96, 160, 4
+    images = []
+    for seed in range(6):
+        s = synth.synth_v1(H, W, C, offs, 500 + seed)
+        images.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
+    opts = seg.default_options(clip_inputs=1)
+    single = seg.Merger(H, W, C, len(offs))
+    want = [single.segment(cp, sp, offs, opts) for cp, sp in images]
+    pool = seg.MergerPool(H, W, C, len(offs), depth=4)
+    # inputs "produced" right before submission on the current stream: a scaled copy
+    fresh = [((cp * 1.0).contiguous(), (sp * 1.0).contiguous()) for cp, sp in images] * 3
+    got = pool.map(fresh, offs, opts)
+    assert len(got) == 18
+    for k, (mask, table, _, st) in enumerate(got):
+        wmask, wtable, _, wst = want[k % 6]
+        assert torch.equal(mask, wmask) and st["num_instances"] == wst["num_instances"]
+        assert torch.equal(table[: st["num_instances"]], wtable[: wst["num_instances"]])
+        assert st["total_logprob"] == wst["total_logprob"]
+    pool.close()
+    single.close()
+    with pytest.raises(RuntimeError):
+        pool.submit(images[0][0], images[0][1], offs, opts)
