@@ -522,8 +522,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // the component contraction needs: gain = omf * log-odds with omf > 0; bias >= 0 (csegment) so
   // that intra-component records (> bias) are always visible and ahead of cross records (< bias);
   // pysegmenter divides (gain + bias) by n1*n2, which only separates the two kinds when bias == 0
+  // (and N <= 2^26: a component's class sums are 2^-32 fixed point in 64 bits, |log p| <= 16)
   if (mode == MN_MODE_COMPONENTS &&
-      !(opts->object_merge_factor >= 1e-20f &&
+      !(N <= (1 << 26) && opts->object_merge_factor >= 1e-20f &&
         (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;

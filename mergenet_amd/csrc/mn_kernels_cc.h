@@ -387,7 +387,8 @@ __device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key,
 // Conditions (a), (b) on every edge; records between components summed into the table:
 // wave-aggregated by key, then collected in a per-block LDS table so that a record shared by the
 // whole boundary of a large instance costs one global insert per block.
-#define MN_CC_EDGE_THREADS 1024
+#define MN_CC_EDGE_THREADS 256   /* measured at 1024x2048: 1024 -> 52.1 us, 512 -> 49.7, 256 -> 47.3 */
+#define MN_CC_EDGE_G 5          /* offsets staged together: 3 -> 52.2 us, 5 -> 52.1, 10 -> 57.1 */
 #define MN_CC_EDGE_SLOTS 256
 __device__ __forceinline__ bool mn_cc_lds_add(u64* s_key, u64* s_sum, const HashTab& T, u64 key,
                                               i64 s) {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
   }
   u64 ckey = MN_EMPTY;
   i64 csum = 0;
-  constexpr int G = 5;                                  // offsets whose loads are in flight together
+  constexpr int G = MN_CC_EDGE_G;                                  // offsets whose loads are in flight together
   for (int k0 = 0; k0 < P.O; k0 += G) {
     float4 v[G];
     int4 rq[G];
