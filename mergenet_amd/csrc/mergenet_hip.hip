@@ -676,9 +676,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // certificate + log-likelihood
   {
     const bool four = P.W % 4 == 0;              // 4 pixels of one row per lane
-    const int vb = (int)grid_for(four ? (size_t)N / 4 : (size_t)N, 256);
+    const int vb = (int)grid_for(four ? (size_t)N / 4 : (size_t)N, four ? MN_VERIFY4_THREADS : 256);
     if (four)
-      hipLaunchKernelGGL(mn_verify_edges4, dim3(vb), dim3(256), 0, st, P, S,
+      hipLaunchKernelGGL(mn_verify_edges4, dim3(vb), dim3(MN_VERIFY4_THREADS), 0, st, P, S,
                          (const unsigned char*)c->cls0, (const int*)c->root, c->partial, c->scalars);
     else
       hipLaunchKernelGGL(mn_verify_edges, dim3(vb), dim3(256), 0, st, P, S,

@@ -228,12 +228,15 @@ __global__ __launch_bounds__(256) void mn_verify_edges(ImgParams P, ObjState S,
 // sameness values and of the neighbours' roots (unaligned), a quarter of the load instructions.
 struct __attribute__((packed, aligned(4))) mn_int4_unaligned { int x, y, z, w; };
 
-__global__ __launch_bounds__(256) void mn_verify_edges4(ImgParams P, ObjState S,
+#ifndef MN_VERIFY4_THREADS
+#define MN_VERIFY4_THREADS 256
+#endif
+__global__ __launch_bounds__(MN_VERIFY4_THREADS) void mn_verify_edges4(ImgParams P, ObjState S,
                                                         const unsigned char* __restrict__ cls0,
                                                         const int* __restrict__ root,
                                                         double* __restrict__ partial,
                                                         int* __restrict__ violations) {
-  __shared__ double sh[3][4];
+  __shared__ double sh[3][MN_VERIFY4_THREADS / 64];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double t_cls = 0.0, t_same = 0.0, t_diff = 0.0;
   int bad = 0, bad_cls = 0;
@@ -312,9 +315,11 @@ __global__ __launch_bounds__(256) void mn_verify_edges4(ImgParams P, ObjState S,
     if (bad_cls) atomicAdd(violations + 3, bad_cls);
   }
   __syncthreads();
-  if (threadIdx.x < 3)
-    partial[(size_t)blockIdx.x * 3 + threadIdx.x] =
-        ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int w = 0; w < MN_VERIFY4_THREADS / 64; w++) t += sh[threadIdx.x][w];
+    partial[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void mn_verify_reduce(int nblocks, const double* __restrict__ partial,
