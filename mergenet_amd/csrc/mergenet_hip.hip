@@ -66,6 +66,8 @@ struct mn_context {
   int* h_scalars;         // pinned
   double* h_lp;           // pinned
   size_t cc_sum_lds;
+  int *cc_tcount, *cc_lcount;   // pixel edges per record: parallel to the components-mode table / list
+  size_t cc_cap_max;
   hipEvent_t ev[10];   // 0-4 phases, 6-9 components-mode kernels
   ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
   int last_valid;
@@ -148,6 +150,10 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->LB.aux, R));
   MN_HIP(dev_alloc(c, &c->touched_list, R));
   MN_HIP(dev_alloc(c, &c->fin_lists, 3 * (size_t)MN_FIN2_MAXR));
+  c->cc_cap_max = next_pow2(N / 8 + 8192);
+  if (c->cc_cap_max > cap) c->cc_cap_max = cap;
+  MN_HIP(dev_alloc(c, &c->cc_tcount, c->cc_cap_max));
+  MN_HIP(dev_alloc(c, &c->cc_lcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->T.key, cap));
   MN_HIP(dev_alloc(c, &c->T.S, cap));
   MN_HIP(dev_alloc(c, &c->T.st, cap));
@@ -200,7 +206,7 @@ extern "C" void mn_destroy(mn_context* c) {
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
-                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->T.key,
+                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
                  c->bg_key, c->lp_out, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
@@ -459,7 +465,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   if (P.W % 4 == 0)
     hipLaunchKernelGGL(mn_cc_edges4, dim3(grid_for((size_t)N / 4, MN_CC_EDGE_THREADS)),
                        dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
-                       c->scalars + 6);
+                       c->scalars + 6, c->cc_tcount, c->partial);
   else
     hipLaunchKernelGGL(mn_cc_edges, dim3(8 * ((grid_for(N, MN_CC_EDGE_THREADS) + 7) / 8)),
                        dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
@@ -468,9 +474,10 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
-  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc);
+  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc,
+                     c->mate);     // `mate` is free in this mode: it keeps the component sizes
   hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
-                     T, c->LA, c->ball, c->gmax, c->cnt);
+                     T, c->LA, c->ball, c->gmax, c->cnt, (const int*)c->cc_tcount, c->cc_lcount);
   MN_HIP(hipGetLastError());
   if (!wait) return 0;             // speculative: the caller finds out at its final synchronisation
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -539,11 +546,12 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     // records between components are few; a table that turns out too small fails the bounded
     // insert, which counts as "not separable" and sends the image to the rounds
     size_t cap = next_pow2((size_t)N / 8 + 8192);
-    if (cap > c->cap) cap = c->cap;
+    if (cap > c->cc_cap_max) cap = c->cc_cap_max;
     c->cc_cap = cap;
     fills.add(c->T.key, cap * sizeof(u64), 0xFF);
     fills.add(c->T.S, cap * sizeof(i64), 0);
     fills.add(c->T.touched, cap, 0);
+    fills.add(c->cc_tcount, cap * sizeof(int), 0);
     fills.add(c->label, (size_t)N * sizeof(int), 0xFF);   // finisher's object -> record map
     // every best-record slot, not only the components': if more records are left than the
     // finisher takes, the rounds go on from this list and look at all N slots
@@ -646,7 +654,8 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       hipLaunchKernelGGL(mn_finisher_lds, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S,
                          cur, R, c->label, c->fin_lists, c->cnt, max_steps,
                          speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr,
-                         (const int*)(c->scalars + 6), finish_limit);
+                         (const int*)(c->scalars + 6), finish_limit,
+                         (mode == MN_MODE_COMPONENTS && rounds == 0) ? c->cc_lcount : (int*)nullptr);
     } else {
       hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
                          c->touched_list, c->cnt, max_steps);
@@ -674,7 +683,19 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                      (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
                      c->root, d_mask, d_partition, d_object_class);
   // certificate + log-likelihood
-  {
+  if (mode == MN_MODE_COMPONENTS && rounds == 0 && P.W % 4 == 0 && R <= MN_FIN2_MAXR) {
+    // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
+    // for the components and the finisher what the merged records moved (mn_cc_certificate)
+    const int nbe = (int)grid_for((size_t)N / 4, MN_CC_EDGE_THREADS), nbc = (int)grid_for(N, 256);
+    double* pcls = c->partial + 2 * (size_t)nbe;
+    hipLaunchKernelGGL(mn_cc_certificate, dim3(nbc), dim3(256), 0, st, P, S,
+                       (const unsigned char*)c->cls0, (const int*)c->mate, pcls, c->scalars);
+    hipLaunchKernelGGL(mn_cc_cert_reduce, dim3(1), dim3(256), 0, st, nbe, (const double*)c->partial, nbc,
+                       (const double*)pcls, (const Counters*)c->cnt, P.omf, c->lp_out, c->scalars);
+    if (R > 0)
+      hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
+                         c->scalars, speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr);
+  } else {
     const bool four = P.W % 4 == 0;              // 4 pixels of one row per lane
     const int vb = (int)grid_for(four ? (size_t)N / 4 : (size_t)N, four ? MN_VERIFY4_THREADS : 256);
     if (four)

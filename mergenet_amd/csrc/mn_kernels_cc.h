@@ -369,13 +369,16 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
 // insert with a bounded probe sequence: the table is sized for "few records between components";
 // an input that is not separable may produce millions, so a full table must end the sweep (the
 // caller falls back) instead of spinning
-__device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key, i64 s) {
+__device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key, i64 s,
+                                                      int* __restrict__ tcount = nullptr,
+                                                      int count = 0) {
   unsigned slot = mn_hash(key) & T.mask;
 #pragma unroll 1
   for (int t = 0; t < 256; t++) {
     const u64 prev = atomicCAS(&T.key[slot], MN_EMPTY, key);
     if (prev == MN_EMPTY || prev == key) {
       atomicAdd(reinterpret_cast<u64*>(&T.S[slot]), (u64)s);
+      if (tcount) atomicAdd(&tcount[slot], count);      // pixel edges folded into this record
       T.touched[slot] = 1;
       return true;
     }
@@ -401,6 +404,24 @@ __device__ __forceinline__ bool mn_cc_lds_add(u64* s_key, u64* s_sum, const Hash
     h = (h + 1) & (MN_CC_EDGE_SLOTS - 1);
   }
   return mn_tab_insert_bounded(T, key, s);    // block table crowded: straight to the global one
+}
+
+// with the number of pixel edges per record alongside the sum (edge sweep of the fast certificate)
+__device__ __forceinline__ bool mn_cc_lds_add_cnt(u64* s_key, u64* s_sum, int* s_cnt, const HashTab& T,
+                                                  int* __restrict__ tcount, u64 key, i64 s, int n) {
+  unsigned h = (mn_hash(key) >> 7) & (MN_CC_EDGE_SLOTS - 1);
+#pragma unroll 1
+  for (int t = 0; t < 32; t++) {
+    u64 prev = s_key[h];
+    if (prev == MN_EMPTY) prev = atomicCAS(&s_key[h], MN_EMPTY, key);
+    if (prev == MN_EMPTY || prev == key) {
+      atomicAdd(&s_sum[h], (u64)s);
+      atomicAdd(&s_cnt[h], n);
+      return true;
+    }
+    h = (h + 1) & (MN_CC_EDGE_SLOTS - 1);
+  }
+  return mn_tab_insert_bounded(T, key, s, tcount, n);
 }
 
 __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, ObjState S, HashTab T,
@@ -477,13 +498,26 @@ __device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) 
   return make_int4(t.x, t.y, t.z, t.w);
 }
 
+// This sweep also lays the ground for the certificate and the log-likelihood of the final
+// partition, so that no further sweep over the sameness planes is needed after the merge
+// (mn_cc_certificate): per block the float64 sums  sum log v  over edges inside components and
+// sum log(1-v)  over edges between components (partial[2b], partial[2b+1]), and per record the
+// number of pixel edges folded into it (tcount, parallel to the table).
 __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, ObjState S, HashTab T,
                                                                    const unsigned char* __restrict__ cls0,
-                                                                   int* __restrict__ violations) {
+                                                                   int* __restrict__ violations,
+                                                                   int* __restrict__ tcount,
+                                                                   double* __restrict__ partial) {
   __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
   __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
-  if (threadIdx.x < MN_CC_EDGE_SLOTS) { s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; }
+  __shared__ int s_cnt[MN_CC_EDGE_SLOTS];
+  __shared__ double s_part[2][MN_CC_EDGE_THREADS / 64];
+  if (threadIdx.x < MN_CC_EDGE_SLOTS) {
+    s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
+  }
   __syncthreads();
+  double t_same = 0.0, t_diff = 0.0;
+  int ccnt = 0;
   const int n4 = P.N >> 2;
   const int i = blockIdx.x * MN_CC_EDGE_THREADS + threadIdx.x;
   const bool live = i < n4;
@@ -529,14 +563,21 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
     auto edge = [&](int col, float raw, int q, int own) {
       if (col < 0 || col >= P.W) return;
       const float x = mn_same_value(P, raw);                         // margins: see mn_cc_edges
-      if (q == own) { if (!(x >= P.sep_hi)) bad++; return; }         // (a)
+      if (q == own) {                                                // (a)
+        if (!(x >= P.sep_hi)) bad++;
+        t_same += (double)logf(x);
+        return;
+      }
       if (!(x <= P.sep_lo)) bad++;                                   // (b)
       const u64 key = mn_key(own, q);
-      const i64 sx = mn_edge_fixed(x);
-      if (key == ckey) { csum += sx; return; }
-      if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+      const float ld = mn_log1m(x);
+      t_diff += (double)ld;
+      const i64 sx = __float2ll_rn((logf(x) - ld) * (float)MN_FIX_ONE);   // = mn_edge_fixed(x)
+      if (key == ckey) { csum += sx; ccnt++; return; }
+      if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) bad++;
       ckey = key;
       csum = sx;
+      ccnt = 1;
     };
 #pragma unroll
     for (int j = 0; j < G; j++) {
@@ -547,18 +588,104 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
       edge(first[j] + 3, v[j].w, rq[j].w, root3);
     }
   }
-  if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+  if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) bad++;
+  for (int off = 32; off > 0; off >>= 1) {
+    bad += __shfl_xor(bad, off);
+    t_same += __shfl_xor(t_same, off);
+    t_diff += __shfl_xor(t_diff, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (bad) atomicAdd(violations, bad);
+    s_part[0][threadIdx.x >> 6] = t_same;
+    s_part[1][threadIdx.x >> 6] = t_diff;
+  }
   __syncthreads();
+  int late = 0;
   if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
-    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x])) bad++;
-  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
-  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
+    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x], tcount, s_cnt[threadIdx.x]))
+      late = 1;
+  if (late) atomicAdd(violations, 1);
+  if (threadIdx.x < 2) {                                // block order: the sum is reproducible
+    double t = 0.0;
+    for (int w = 0; w < MN_CC_EDGE_THREADS / 64; w++) t += s_part[threadIdx.x][w];
+    partial[(size_t)blockIdx.x * 2 + threadIdx.x] = t;
+  }
+}
+
+// After the merge: what the sweeps above could not know.  One lane per pixel, work only at the
+// component roots (compsize > 0): the class term of the log-likelihood  lp[cls]  of every final
+// object, and the pixels whose own arg-max class differs from their final object's class (a
+// component has one class, so that is the component's size or nothing).
+__global__ __launch_bounds__(256) void mn_cc_certificate(ImgParams P, ObjState S,
+                                                         const unsigned char* __restrict__ cls0,
+                                                         const int* __restrict__ compsize,
+                                                         double* __restrict__ partial_cls,
+                                                         int* __restrict__ violations) {
+  __shared__ double sh[4];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double t_cls = 0.0;
+  int bad_cls = 0;
+  if (p < P.N) {
+    const int cs = compsize[p];
+    if (cs > 0) {
+      int f = p;
+      while (S.parent[f] != f) f = S.parent[f];
+      const int oc = S.ocls[f];
+      if (cls0[p] != oc) bad_cls = cs;
+      if (f == p) t_cls = (double)mn_obj_lp(P, S, S.lpvalid[p] != 0, p, oc);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    t_cls += __shfl_xor(t_cls, off);
+    bad_cls += __shfl_xor(bad_cls, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = t_cls;
+    if (bad_cls) atomicAdd(violations + 3, bad_cls);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) partial_cls[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// total = class term + omf * (sum over edges: log v inside final objects, log(1-v) between them).
+// The edge sweep summed it for the components; a record merged afterwards moves its edges from
+// "between" to "inside", i.e. adds its log-odds sum, and makes each of them an edge whose sign
+// contradicts the partition (the finisher accumulated both).
+__global__ __launch_bounds__(256) void mn_cc_cert_reduce(int nb_edges, const double* __restrict__ partial_edges,
+                                                         int nb_cls, const double* __restrict__ partial_cls,
+                                                         const Counters* __restrict__ cnt, float omf,
+                                                         double* __restrict__ out,
+                                                         int* __restrict__ violations) {
+  __shared__ double sh[3][256];
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nb_cls; b += 256) a[0] += partial_cls[b];
+  for (int b = threadIdx.x; b < nb_edges; b += 256) {
+    a[1] += partial_edges[(size_t)b * 2];
+    a[2] += partial_edges[(size_t)b * 2 + 1];
+  }
+  for (int j = 0; j < 3; j++) sh[j][threadIdx.x] = a[j];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int j = 0; j < 3; j++) sh[j][threadIdx.x] += sh[j][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double moved = (double)cnt->merged_S * (1.0 / MN_FIX_ONE);
+    out[0] = sh[0][0] + ((sh[2][0] + sh[1][0]) + moved) * (double)omf;
+    out[1] = sh[0][0]; out[2] = sh[1][0]; out[3] = sh[2][0];
+    if (cnt->merged_E) atomicAdd(violations, cnt->merged_E);
+  }
 }
 
 __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
-                                                    const i64* __restrict__ lp_acc) {
+                                                    const i64* __restrict__ lp_acc,
+                                                    int* __restrict__ compsize) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.N || S.parent[p] != p) return;
+  if (p >= P.N) return;
+  const bool is_root = S.parent[p] == p;
+  compsize[p] = is_root ? S.osize[p] : 0;  // kept for mn_cc_certificate: osize grows in the merge
+  if (!is_root) return;
   if (S.osize[p] <= 1) return;            // a lone pixel keeps reading its class planes
   for (int c = 0; c < P.C; c++)
     S.lpsum[(size_t)c * P.N + p] = (float)((double)lp_acc[(size_t)c * P.N + p] * (1.0 / MN_LP_FIX));

@@ -226,7 +226,7 @@ __device__ __forceinline__ unsigned mn_fin_word(float st) {
 __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     ImgParams P, ObjState S, RecList L, int R, int* __restrict__ maprec, int* __restrict__ lists,
     Counters* __restrict__ cnt, long long max_steps, const int* __restrict__ spec_records,
-    const int* __restrict__ spec_violations, int spec_limit) {
+    const int* __restrict__ spec_violations, int spec_limit, int* __restrict__ lcount) {
   if (spec_records) {
     R = *spec_records;
     if (R > spec_limit || *spec_violations != 0) return;          // uniform
@@ -263,6 +263,10 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
 
   long long steps = 0;
   int merges = 0;
+  // `lcount` (components mode): pixel edges per record; what the merged records held is handed
+  // to mn_cc_cert_reduce (lane 0 keeps the totals)
+  i64 merged_S = 0;
+  int merged_E = 0;
 #ifdef MN_FIN_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
         sh_valid = swap ? ((fld[3] ? 1 : 0) | (fld[2] ? 2 : 0)) : ((fld[2] ? 1 : 0) | (fld[3] ? 2 : 0));
         sh_do_merge = 1 + mc;
         lw[bi] = 0; lu[bi] = DEAD; lv[bi] = DEAD;
+        if (lcount) { merged_S += L.S[bi]; merged_E += lcount[bi]; }
       }
       }
     }
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
         const int mrec = maprec[o];
         if (mrec >= 0) {
           L.S[mrec] += L.S[i];
+          if (lcount) lcount[mrec] += lcount[i];
           lw[i] = 0; lu[i] = DEAD; lv[i] = DEAD;
           t = mrec;
         } else {
@@ -439,5 +445,7 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     cnt->finisher_steps = (int)(steps > 0x7FFFFFFF ? 0x7FFFFFFF : steps);
     cnt->finisher_merges = merges;
     cnt->n_merged = merges;
+    cnt->merged_S = merged_S;
+    cnt->merged_E = merged_E;
   }
 }

@@ -48,13 +48,14 @@ struct Counters {
   int finisher_steps;
   int finisher_merges;
   int error;
-  int pad;
+  int merged_E;          // pixel edges of the records the LDS finisher merged (fast certificate)
+  long long merged_S;    // and their summed log-odds, fixed point
 };
 
 // ---- several memsets in one launch --------------------------------------------------------------
 // A dozen hipMemsetAsync calls per image cost ~6 us each plus the gaps between them, which is a
 // tenth of an image in components mode: the regions are filled by one kernel instead.
-#define MN_FILL_JOBS 12
+#define MN_FILL_JOBS 16
 struct FillJobs {
   void* ptr[MN_FILL_JOBS];
   unsigned long long bytes[MN_FILL_JOBS];
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(256) void mn_build_from_pixels(ImgParams P, ObjStat
 __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashTab T, RecList L,
                                                   u64* __restrict__ ball,
                                                   unsigned* __restrict__ gmax,
-                                                  Counters* __restrict__ cnt) {
+                                                  Counters* __restrict__ cnt,
+                                                  const int* __restrict__ tcount = nullptr,
+                                                  int* __restrict__ lcount = nullptr) {
   __shared__ int sh_w[4][4];
   __shared__ int sh_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
     L.st[idx] = st;
     L.fr[idx] = f;
     L.aux[idx] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));
+    if (lcount) lcount[idx] = tcount[slot];           // pixel edges per record (components mode)
     if (st >= 0.0f) {
       // a plain look first: most records lose against what is already there (an object has tens
       // of records, a running maximum changes ~ln(n) times), and a lost race only costs the atomic
