@@ -464,3 +464,21 @@ def test_components_mode_record_table_overflow_falls_back(oracle):
     assert st["mode_used"] == seg.MN_MODE_ROUNDS
     assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
     assert oracle.same_partition(part, ref.partition), st
+
+
+@pytest.mark.parametrize("name", ["cseg_synth_512x1024_s1000", "cseg_synth_512x1024_s1001",
+                                  "cseg_synth_1024x2048_cfg2", "cseg_synth_1024x2048_s1002"])
+def test_components_certificate_equals_the_sweep_over_the_final_partition(oracle, name):
+    """Components mode takes certificate and log-likelihood from the contraction's own sweep plus
+    what the finisher merged; the rounds recompute them by a sweep over the final partition.  Same
+    partition => same violation counts, log-likelihood equal to float32-sum accuracy."""
+    g = gu.load(name)
+    mask_c, classes_c, part_c, st_c = _run(g, seg.MN_MODE_COMPONENTS)
+    mask_r, classes_r, part_r, st_r = _run(g, seg.MN_MODE_ROUNDS)
+    assert st_c["mode_used"] == seg.MN_MODE_COMPONENTS and st_r["mode_used"] == seg.MN_MODE_ROUNDS
+    assert oracle.same_partition(part_c, part_r)
+    assert st_c["cert_edge_violations"] == st_r["cert_edge_violations"]
+    assert st_c["cert_class_violations"] == st_r["cert_class_violations"]
+    assert st_c["cert_record_violations"] == st_r["cert_record_violations"]
+    assert st_c["certified"] == st_r["certified"]
+    assert abs(st_c["total_logprob"] - st_r["total_logprob"]) <= 1e-7 * abs(st_r["total_logprob"])
