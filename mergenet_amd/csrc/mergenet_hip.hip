@@ -686,9 +686,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   if (mode == MN_MODE_COMPONENTS && rounds == 0 && P.W % 4 == 0 && R <= MN_FIN2_MAXR) {
     // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
     // for the components and the finisher what the merged records moved (mn_cc_certificate)
-    const int nbe = (int)grid_for((size_t)N / 4, MN_CC_EDGE_THREADS), nbc = (int)grid_for(N, 256);
+    const int nbe = (int)grid_for((size_t)N / 4, MN_CC_EDGE_THREADS), nbc = (int)grid_for(N, MN_CC_CERT_THREADS);
     double* pcls = c->partial + 2 * (size_t)nbe;
-    hipLaunchKernelGGL(mn_cc_certificate, dim3(nbc), dim3(256), 0, st, P, S,
+    hipLaunchKernelGGL(mn_cc_certificate, dim3(nbc), dim3(MN_CC_CERT_THREADS), 0, st, P, S,
                        (const unsigned char*)c->cls0, (const int*)c->mate, pcls, c->scalars);
     hipLaunchKernelGGL(mn_cc_cert_reduce, dim3(1), dim3(256), 0, st, nbe, (const double*)c->partial, nbc,
                        (const double*)pcls, (const Counters*)c->cnt, P.omf, c->lp_out, c->scalars);

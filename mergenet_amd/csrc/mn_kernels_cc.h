@@ -616,12 +616,13 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
 // component roots (compsize > 0): the class term of the log-likelihood  lp[cls]  of every final
 // object, and the pixels whose own arg-max class differs from their final object's class (a
 // component has one class, so that is the component's size or nothing).
-__global__ __launch_bounds__(256) void mn_cc_certificate(ImgParams P, ObjState S,
+#define MN_CC_CERT_THREADS 1024
+__global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(ImgParams P, ObjState S,
                                                          const unsigned char* __restrict__ cls0,
                                                          const int* __restrict__ compsize,
                                                          double* __restrict__ partial_cls,
                                                          int* __restrict__ violations) {
-  __shared__ double sh[4];
+  __shared__ double sh[MN_CC_CERT_THREADS / 64];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double t_cls = 0.0;
   int bad_cls = 0;
@@ -644,7 +645,11 @@ __global__ __launch_bounds__(256) void mn_cc_certificate(ImgParams P, ObjState S
     if (bad_cls) atomicAdd(violations + 3, bad_cls);
   }
   __syncthreads();
-  if (threadIdx.x == 0) partial_cls[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < MN_CC_CERT_THREADS / 64; w++) t += sh[w];
+    partial_cls[blockIdx.x] = t;
+  }
 }
 
 // total = class term + omf * (sum over edges: log v inside final objects, log(1-v) between them).
