@@ -19,6 +19,9 @@
 #include "mn_kernels_prepare.h"
 #include "mn_kernels_cc.h"
 
+// Counters | 8 int scalars | 4 doubles, each part 16-byte aligned
+#define MN_STAT_BYTES ((((sizeof(Counters) + 15) & ~(size_t)15)) + 8 * sizeof(int) + 4 * sizeof(double))
+
 #define MN_MAX_SUBROUNDS 64
 
 static thread_local int g_last_status = MN_OK;
@@ -66,6 +69,10 @@ struct mn_context {
   int* h_scalars;         // pinned
   double* h_lp;           // pinned
   size_t cc_sum_lds;
+  // counters, scalars and log-likelihood outputs live in ONE device block mirrored by ONE pinned
+  // host block, so that the statistics of an image come back in a single copy
+  unsigned char* statblk;
+  unsigned char* h_statblk;
   int *cc_tcount, *cc_lcount;   // pixel edges per record: parallel to the components-mode table / list
   size_t cc_cap_max;
   hipEvent_t ev[10];   // 0-4 phases, 6-9 components-mode kernels
@@ -160,16 +167,21 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->T.touched, cap));
   MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
   MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
-  MN_HIP(dev_alloc(c, &c->cnt, 1));
-  MN_HIP(dev_alloc(c, &c->scalars, 8));
+  {
+    const size_t o_sc = (sizeof(Counters) + 15) & ~(size_t)15, o_lp = o_sc + 8 * sizeof(int);
+    MN_HIP(dev_alloc(c, &c->statblk, MN_STAT_BYTES));
+    c->cnt = reinterpret_cast<Counters*>(c->statblk);
+    c->scalars = reinterpret_cast<int*>(c->statblk + o_sc);
+    c->lp_out = reinterpret_cast<double*>(c->statblk + o_lp);
+    MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_statblk), MN_STAT_BYTES));
+    c->h_cnt = reinterpret_cast<Counters*>(c->h_statblk);
+    c->h_scalars = reinterpret_cast<int*>(c->h_statblk + o_sc);
+    c->h_lp = reinterpret_cast<double*>(c->h_statblk + o_lp);
+  }
   MN_HIP(dev_alloc(c, &c->gmax, 64));
   MN_HIP(dev_alloc(c, &c->theta, 4));
   MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
-  MN_HIP(dev_alloc(c, &c->lp_out, 4));
-  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cnt), sizeof(Counters)));
-  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 8 * sizeof(int)));
-  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_lp), 4 * sizeof(double)));
   for (int i = 0; i < 10; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   return MN_OK;
 }
@@ -207,13 +219,11 @@ extern "C" void mn_destroy(mn_context* c) {
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
                  c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->T.key,
-                 c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->cnt, c->scalars,
-                 c->bg_key, c->lp_out, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
+                 c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->statblk,
+                 c->bg_key, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
-  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
-  if (c->h_lp) (void)hipHostFree(c->h_lp);
+  if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   for (int i = 0; i < 10; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   free(c);
@@ -715,9 +725,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   c->last_params = P;
   c->last_valid = 1;
 
-  MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-  MN_HIP(hipMemcpyAsync(c->h_lp, c->lp_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_statblk, c->statblk, MN_STAT_BYTES, hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
   if (speculate) {
     if (c->h_scalars[6] != 0) return MN_RETRY_ROUNDS;
