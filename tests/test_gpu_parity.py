@@ -482,3 +482,50 @@ def test_components_certificate_equals_the_sweep_over_the_final_partition(oracle
     assert st_c["cert_record_violations"] == st_r["cert_record_violations"]
     assert st_c["certified"] == st_r["certified"]
     assert abs(st_c["total_logprob"] - st_r["total_logprob"]) <= 1e-7 * abs(st_r["total_logprob"])
+
+
+def test_fuzz_components_mode_on_random_shapes_offsets_and_options(oracle):
+    """Random image sizes (tile and 4-pixel-lane borders everywhere), class counts, offset sets
+    (with and without the unit offsets the tile stage uses) and options; components mode forced.
+    Whatever path it ends on, the result must be the oracle's."""
+    rng = np.random.default_rng(20261004)
+    used = {seg.MN_MODE_COMPONENTS: 0, seg.MN_MODE_ROUNDS: 0}
+    for trial in range(24):
+        H = int(rng.integers(8, 72))
+        W = int(rng.integers(8, 150))
+        C = int(rng.integers(2, 13))
+        offs = synth.generate_offsets(int(rng.integers(3, 14)), int(rng.integers(4, 8)))
+        if trial % 3 == 2:                       # an offset list without (0,1) / (1,0)
+            offs = [o for o in offs if abs(o[0]) + abs(o[1]) > 1]
+        noise = float(rng.choice([0.1, 0.2, 0.3]))
+        opts = [(0.0, 1.0, 0.03), (0.3, 1.0, 0.03), (-0.2, 0.7, 0.0), (0.0, 2.0, 0.1)][trial % 4]
+        s = synth.synth_v1(H, W, C, offs, 9000 + trial, noise=noise)
+        ref = oracle.run_csegment(s.class_probs, s.sameness_probs, C, offs, *opts)
+        mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, seg.MN_MODE_COMPONENTS, opts)
+        used[st["mode_used"]] += 1
+        ctx = (trial, H, W, C, offs, noise, opts, st)
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), ctx
+        assert oracle.same_partition(part, ref.partition), ctx
+        assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob), ctx
+    assert used[seg.MN_MODE_COMPONENTS] >= 12, used     # the fast path must be what is mostly tested
+
+
+@pytest.mark.xfail(strict=False, reason="known deviation of the fast modes' second phase: the reference "
+                   "keeps a record at the priority of its last re-score (taken when the objects were "
+                   "smaller), components mode scores the records between components afresh; here one "
+                   "record is non-negative afresh but was last scored negative in the reference, so it is "
+                   "merged here and never looked at there (DESIGN.md section 5).  EXACT mode and, on this "
+                   "input, the rounds give the reference's result.")
+def test_components_mode_known_deviation_stale_record(oracle):
+    """Found by the fuzz test above with only two offsets [(1,0), (-1,5)]: the instances fall
+    into interleaved column components that no offset links.  Kept as a witness."""
+    offs = [(1, 0), (-1, 5)]
+    s = synth.synth_v1(47, 72, 9, offs, 9004, noise=0.1)
+    ref = oracle.run_csegment(s.class_probs, s.sameness_probs, 9, offs, 0.0, 1.0, 0.03)
+    for mode in (seg.MN_MODE_EXACT, seg.MN_MODE_ROUNDS):
+        mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, mode)
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (mode, st)
+    mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, seg.MN_MODE_COMPONENTS)
+    assert st["certified"] == 0          # the flag that says "not proven": it must not claim more
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
+
