@@ -192,6 +192,12 @@ def main():
     KEYS = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_merge",
             "ms_output", "ms_total")
     keys = KEYS
+    # initialisation, not a step: one call loads the kernels and sets their attributes, one
+    # exchange of an empty mask brings up the communicator's channels for the message size used
+    merger.segment(pool_images[0][0], pool_images[0][1], offs, opts)
+    if ex is not None:
+        zmask = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        ex.result(ex.submit(zmask, torch.zeros((1,), dtype=torch.int32, device=dev), 0))
     if args.warmup:
         run_steps(0, args.warmup, main_pool)
     fence()
