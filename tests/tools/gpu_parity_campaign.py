@@ -14,18 +14,21 @@ SEEDS = list(range(int(sys.argv[3]) if len(sys.argv) > 3 else 2000, (int(sys.arg
 NOISE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.15
 VARIANT = sys.argv[6] if len(sys.argv) > 6 else "csegment"     # or "pysegmenter" (options 0, 1/O, 0)
 MODE = int(sys.argv[7]) if len(sys.argv) > 7 else 0            # 0 AUTO, 2 ROUNDS, 3 COMPONENTS
+import os
+INSTANCES = int(os.environ["MN_CAMPAIGN_INSTANCES"]) if "MN_CAMPAIGN_INSTANCES" in os.environ else None
+BIAS = float(os.environ.get("MN_CAMPAIGN_BIAS", "0.03"))       # merge_logprob_bias (csegment variant)
 
 
 def oracle_one(seed):
     from mergenet_amd import synth
     from oracle import checker as ck
     offs = synth.generate_offsets(40, 10)
-    s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE)
+    s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE, num_instances=INSTANCES)
     t = time.time()
     if VARIANT == "pysegmenter":
         r = ck.run_pysegmenter(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0 / len(offs), 0.0)
     else:
-        r = ck.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
+        r = ck.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, BIAS)
     return seed, r.mask, r.object_class, r.total_logprob, time.time() - t
 
 
@@ -37,12 +40,12 @@ if __name__ == "__main__":
         ctx = seg.HostContext(H, W, C, len(offs))
         gpu = {}
         for seed in SEEDS:
-            s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE)
+            s = synth.synth_v1(H, W, C, offs, seed, noise=NOISE, num_instances=INSTANCES)
             if VARIANT == "pysegmenter":
                 o = seg.default_options(mode=MODE, variant=seg.MN_VARIANT_PYSEGMENTER,
                                         object_merge_factor=1.0 / len(offs), merge_logprob_bias=0.0)
             else:
-                o = seg.default_options(mode=MODE)
+                o = seg.default_options(mode=MODE, merge_logprob_bias=BIAS)
             mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
             gpu[seed] = (mask, classes, st)
         while not pending.ready():
@@ -57,4 +60,4 @@ if __name__ == "__main__":
         print("seed %d: %s  mode_used %d  instances gpu %d ref %d  certified %d  gpu %.1f ms  oracle %.0f s  rel.loglik diff %.1e"
               % (seed, "EQUAL" if ok else "DIFFERENT", st["mode_used"], len(classes), len(rcls), st["certified"], st["ms_total"], dt,
                  abs(st["total_logprob"] - rlp) / abs(rlp)), flush=True)
-    print("parity campaign %s mode %d %dx%d noise %.2f: %d/%d images identical to the sequential reference order" % (VARIANT, MODE, H, W, NOISE, eq, len(SEEDS)))
+    print("parity campaign %s mode %d %dx%d noise %.2f instances %s bias %.3f: %d/%d images identical to the sequential reference order" % (VARIANT, MODE, H, W, NOISE, INSTANCES, BIAS, eq, len(SEEDS)))
