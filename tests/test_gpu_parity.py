@@ -529,3 +529,21 @@ def test_components_mode_known_deviation_stale_record(oracle):
     assert st["certified"] == 0          # the flag that says "not proven": it must not claim more
     assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), st
 
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 3, 2), (9, 1, 3, 2), (3, 5, 2, 2), (2, 130, 3, 3), (17, 65, 4, 5),
+                                   (16, 64, 2, 4), (15, 63, 3, 4), (20, 24, 127, 3), (24, 40, 3, 32)])
+def test_components_mode_extreme_shapes(oracle, shape):
+    """One-pixel-wide images, sizes just off the 16x64 tile and the 4-pixel lane, the maximum
+    class count (127) and offset count (32): components mode forced, result = the oracle's."""
+    H, W, C, O = shape
+    if O <= 8:
+        offs = synth.generate_offsets(max(3, min(H, W) // 2 + 2), O)[:O]
+    else:                                      # 32 distinct offsets of one half-plane (no negations)
+        offs = [(di, dj) for di in range(0, 5) for dj in range(-4, 5) if di > 0 or dj > 0][:O]
+    s = synth.synth_v1(H, W, C, offs, 31 + H * W, noise=0.12, num_instances=2)
+    ref = oracle.run_csegment(s.class_probs, s.sameness_probs, C, offs, 0.0, 1.0, 0.03)
+    mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, seg.MN_MODE_COMPONENTS)
+    assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (shape, offs, st)
+    assert oracle.same_partition(part, ref.partition), (shape, st)
+    assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob), (shape, st)
