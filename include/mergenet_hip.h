@@ -71,7 +71,8 @@ typedef struct mn_options {
                                   live records (0 = default 4096)                                */
   int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 32)         */
   float prune_threshold;       /* pysegmenter prune threshold (segmenter.py:351; default 200)    */
-  int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) */
+  int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) and
+                                  the certificate; 0: skip both (total_logprob NaN, certified 0)  */
   int no_handover_refresh;     /* ROUNDS: 1 = keep stored priorities when the finisher takes over  */
   int band_permille;           /* ROUNDS: a round merges only records whose gain is >= this many
                                   thousandths of the round's best gain (0 = default 100, <0 = off;

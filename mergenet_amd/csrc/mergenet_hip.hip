@@ -692,8 +692,11 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
                      (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
                      c->root, d_mask, d_partition, d_object_class);
-  // certificate + log-likelihood
-  if (mode == MN_MODE_COMPONENTS && rounds == 0 && P.W % 4 == 0 && R <= MN_FIN2_MAXR) {
+  // certificate + log-likelihood (skipped on request: compute_logprob = 0, the drop-in entry's
+  // setting -- the reference's c_run_segmentation returns neither)
+  const bool want_cert = opts->compute_logprob != 0;
+  if (!want_cert) {
+  } else if (mode == MN_MODE_COMPONENTS && rounds == 0 && P.W % 4 == 0 && R <= MN_FIN2_MAXR) {
     // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
     // for the components and the finisher what the merged records moved (mn_cc_certificate)
     const int nbe = (int)grid_for((size_t)N / 4, MN_CC_EDGE_THREADS), nbc = (int)grid_for(N, MN_CC_CERT_THREADS);
@@ -742,14 +745,14 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     stats->cert_edge_violations = c->h_scalars[0];
     stats->cert_class_violations = c->h_scalars[3];
     stats->cert_record_violations = c->h_scalars[4];
-    stats->certified = (c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
+    stats->certified = (want_cert && c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
     stats->num_instances = c->h_scalars[1];
     stats->num_objects = c->h_scalars[2];
     stats->rounds = rounds;
     stats->finisher_steps = c->h_cnt->finisher_steps;
     stats->initial_records = R0;
     stats->merges = merges;
-    stats->total_logprob = c->h_lp[0];
+    stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
     (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;

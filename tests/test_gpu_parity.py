@@ -547,3 +547,14 @@ def test_components_mode_extreme_shapes(oracle, shape):
     assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (shape, offs, st)
     assert oracle.same_partition(part, ref.partition), (shape, st)
     assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob), (shape, st)
+
+
+def test_compute_logprob_off_skips_certificate_but_not_the_result(oracle):
+    g = gu.load("cseg_synth_128x256")
+    for mode in (seg.MN_MODE_COMPONENTS, seg.MN_MODE_ROUNDS):
+        mask, classes, part, st = _run(g, mode, compute_logprob=0)
+        assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+        assert np.isnan(st["total_logprob"]) and st["certified"] == 0
+        mask1, classes1, part1, st1 = _run(g, mode)
+        assert np.array_equal(mask, mask1) and classes == classes1
+        assert np.isfinite(st1["total_logprob"])
