@@ -140,6 +140,7 @@ def main():
     # contention, not the kernels; the pipelined rate is reported beside the line (`pipelined`).
     depth = max(1, args.pipeline)
     merger = seg.Merger(H, W, C, O, device=local_rank)
+    mergers2 = [merger, seg.Merger(H, W, C, O, device=local_rank)]
     main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode)
@@ -168,9 +169,18 @@ def main():
             last = (mask, table, st, slot)
 
         if pool is None:
+            # one stream, two contexts: the launch of step i+1 precedes the read-back of step i,
+            # so the host round trip of an image is hidden while kernels of different images
+            # still run one after the other (their HIP-event durations stay those of the kernels)
+            prev = None
             for i in range(first, first + count):
                 cp, sp = pool_images[i % POOL]
-                collect(merger.segment(cp, sp, offs, opts))
+                cur = mergers2[i % 2].segment_async(cp, sp, offs, opts)
+                if prev is not None:
+                    collect(prev.result())
+                prev = cur
+            if prev is not None:
+                collect(prev.result())
         else:
             window = deque()
             for i in range(first, first + count):
@@ -327,6 +337,9 @@ def main():
                                    "in rotation)" % POOL,
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
                        "pipeline_depth": depth,
+                       "host_overlap": "launch of step i+1 queued before the read-back of step i "
+                                       "(mn_segment_launch / mn_segment_finish, two contexts, ONE "
+                                       "stream: kernels of different images do not overlap)",
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
                        "exchange": ("one all_gather per step of int16 masks + class tables over RCCL, "

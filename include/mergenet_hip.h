@@ -137,6 +137,20 @@ int mn_segment_device(mn_context* ctx, const float* d_class_pred, int class_dim,
                       int num_classes, const int* offset_list, int* d_mask, int* d_object_class,
                       int* d_partition, const mn_options* opts, void* stream, mn_stats* stats);
 
+/* The same in two halves, for callers that keep the GPU busy across images: mn_segment_launch
+ * queues one image and returns -- in components mode (the default for large images) without
+ * having waited for anything; mn_segment_finish waits, reads the verdict (redoing the image on the
+ * ordinary path if the speculative attempt does not hold) and fills `stats`.  Between the two the
+ * context is busy and inputs, outputs and stream must stay alive; with two contexts on one stream
+ * the launch of image i+1 can precede the finish of image i, which hides the host round trip
+ * without letting kernels of different images overlap.  A negative return of mn_segment_launch
+ * leaves nothing pending. */
+int mn_segment_launch(mn_context* ctx, const float* d_class_pred, int class_dim,
+                      const float* d_adj_pred, int offset_dim, int img_width, int img_height,
+                      int num_classes, const int* offset_list, int* d_mask, int* d_object_class,
+                      int* d_partition, const mn_options* opts, void* stream);
+int mn_segment_finish(mn_context* ctx, mn_stats* stats);
+
 /* Phase A alone (per-pixel class log-probs + argmax, per-edge log-odds and initial priorities,
  * best initial record per pixel).  Used by bench.py / profiles to time the affinity-scoring pass
  * against the HBM roofline, and by tests to compare phase-A arrays with the oracle.

@@ -76,6 +76,22 @@ struct mn_context {
   int *cc_tcount, *cc_lcount;   // pixel edges per record: parallel to the components-mode table / list
   size_t cc_cap_max;
   hipEvent_t ev[10];   // 0-4 phases, 6-9 components-mode kernels
+  // mn_segment_launch / mn_segment_finish: what the second half needs of the first
+  struct Pending {
+    int active;            // 0 none, 1 kernels queued and verdict unread, 2 finished in launch
+    int rc;
+    int mode, rounds, finish_limit, N;
+    long long R0;
+    bool speculate, want_cert;
+    const float *d_class, *d_adj;
+    int class_dim, offset_dim, W, H, num_classes;
+    int offs[2 * MN_MAX_OFFSETS];
+    int *d_mask, *d_objcls, *d_part;
+    mn_options opts;
+    void* stream;
+    mn_stats stats;
+  } pend;
+  hipEvent_t ev_done;
   ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
   int last_valid;
   // staging for the host-pointer entry points
@@ -183,6 +199,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
   for (int i = 0; i < 10; i++) MN_HIP(hipEventCreate(&c->ev[i]));
+  MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   return MN_OK;
 }
 
@@ -226,6 +243,7 @@ extern "C" void mn_destroy(mn_context* c) {
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   for (int i = 0; i < 10; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   free(c);
 }
 
@@ -503,17 +521,65 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
 // Internal verdicts of a speculative attempt (never returned to the caller).
 #define MN_RETRY_ROUNDS 1001   /* not sign-separable: redo with the rounds            */
 #define MN_RETRY_WAIT 1002     /* more records than the finisher takes: redo, waiting for the count */
+#define MN_PENDING 1003        /* deferred: everything queued, mn_segment_finish reads the verdict   */
 
 // One attempt.  `speculate`: in components mode the host does not wait for the record count and
 // the separability verdict in the middle of the image; finisher and output are queued behind the
 // contraction and everything is read at the one synchronisation at the end.  Sign-separable maps
 // with few components -- the case the mode exists for -- are done then; otherwise a verdict above
 // is returned and mn_segment_device runs the attempt again on the ordinary path.
+// After the stream has drained: verdict of a speculative attempt, then the statistics.
+static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bool speculate,
+                             int finish_limit, int N, long long R0, int rounds, bool want_cert,
+                             mn_stats* stats) {
+  if (speculate) {
+    if (c->h_scalars[6] != 0) return MN_RETRY_ROUNDS;
+    if (c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
+  }
+  const long long merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
+  const int rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
+  if (stats) {
+    stats->status = rc;
+    stats->mode_used = mode;
+    const bool cert_opts = opts->object_merge_factor > 0.0f &&
+                           (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
+                                                                 : opts->merge_logprob_bias == 0.0f);
+    stats->cert_edge_violations = c->h_scalars[0];
+    stats->cert_class_violations = c->h_scalars[3];
+    stats->cert_record_violations = c->h_scalars[4];
+    stats->certified = (want_cert && c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
+    stats->num_instances = c->h_scalars[1];
+    stats->num_objects = c->h_scalars[2];
+    stats->rounds = rounds;
+    stats->finisher_steps = c->h_cnt->finisher_steps;
+    stats->initial_records = R0;
+    stats->merges = merges;
+    stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
+    stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+    if (mode == MN_MODE_COMPONENTS) {
+      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); stats->ms_cc_label = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_edges = ms;
+    }
+  }
+  g_last_status = rc;
+  return rc;
+}
+
+// `defer` (with a speculative attempt only): return MN_PENDING as soon as everything is queued;
+// the caller reads back later with segment_read_back after waiting for ev_done.
 static int segment_attempt(mn_context* c, const float* d_class_pred, int class_dim,
                            const float* d_adj_pred, int offset_dim, int W, int H,
                            int num_classes, const int* offset_list, int* d_mask,
                            int* d_object_class, int* d_partition, const mn_options* opts,
-                           void* stream, mn_stats* stats, int force_mode, bool speculate) {
+                           void* stream, mn_stats* stats, int force_mode, bool speculate,
+                           bool defer = false) {
   mn_options defaults;
   if (!opts) { mn_default_options(&defaults); opts = &defaults; }
   int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
@@ -729,44 +795,64 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   c->last_valid = 1;
 
   MN_HIP(hipMemcpyAsync(c->h_statblk, c->statblk, MN_STAT_BYTES, hipMemcpyDeviceToHost, st));
+  if (defer && speculate) {
+    MN_HIP(hipEventRecord(c->ev_done, st));
+    c->pend.mode = mode; c->pend.rounds = rounds; c->pend.finish_limit = finish_limit; c->pend.N = N;
+    c->pend.R0 = R0; c->pend.speculate = true; c->pend.want_cert = want_cert;
+    return MN_PENDING;
+  }
   MN_HIP(hipStreamSynchronize(st));
-  if (speculate) {
-    if (c->h_scalars[6] != 0) return MN_RETRY_ROUNDS;
-    if (c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
+  (void)merges;
+  return segment_read_back(c, opts, mode, speculate, finish_limit, N, R0, rounds, want_cert, stats);
+}
+
+// First half: queue everything for one image and return.  In components mode (the default for
+// large images) nothing has been waited for when this returns; other modes run to completion here.
+// The context is busy until mn_segment_finish; inputs and outputs must stay alive until then.
+extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int class_dim,
+                                 const float* d_adj_pred, int offset_dim, int W, int H,
+                                 int num_classes, const int* offset_list, int* d_mask,
+                                 int* d_object_class, int* d_partition, const mn_options* opts,
+                                 void* stream) {
+  if (!c || c->pend.active) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+  mn_context::Pending& q = c->pend;
+  if (opts) q.opts = *opts; else mn_default_options(&q.opts);
+  q.d_class = d_class_pred; q.class_dim = class_dim; q.d_adj = d_adj_pred; q.offset_dim = offset_dim;
+  q.W = W; q.H = H; q.num_classes = num_classes;
+  q.d_mask = d_mask; q.d_objcls = d_object_class; q.d_part = d_partition; q.stream = stream;
+  if (offset_list && offset_dim > 0 && offset_dim <= MN_MAX_OFFSETS)
+    memcpy(q.offs, offset_list, sizeof(int) * 2 * (size_t)offset_dim);
+  const int rc = segment_attempt(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
+                                 offset_list, d_mask, d_object_class, d_partition, &q.opts, stream,
+                                 &q.stats, 0, true, true);
+  if (rc == MN_PENDING) { q.active = 1; return MN_OK; }
+  if (rc < 0 && rc != MN_ERR_NO_BACKGROUND) return rc;   // rejected or failed: nothing is pending
+  q.active = 2;                       // ran to completion on the ordinary path
+  q.rc = rc;
+  return MN_OK;
+}
+
+// Second half: wait for the image queued by mn_segment_launch, read the verdict (a speculative
+// attempt that does not hold is redone here on the ordinary path) and fill `stats`.
+extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
+  if (!c || !c->pend.active) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+  mn_context::Pending& q = c->pend;
+  int rc;
+  if (q.active == 2) {
+    rc = q.rc;
+  } else {
+    MN_HIP(hipSetDevice(c->device));
+    MN_HIP(hipEventSynchronize(c->ev_done));
+    memset(&q.stats, 0, sizeof(q.stats));
+    rc = segment_read_back(c, &q.opts, q.mode, true, q.finish_limit, q.N, q.R0, q.rounds, q.want_cert,
+                           &q.stats);
+    if (rc == MN_RETRY_ROUNDS || rc == MN_RETRY_WAIT)
+      rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
+                           q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
+                           rc == MN_RETRY_ROUNDS ? MN_MODE_ROUNDS : 0, false);
   }
-  merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
-  rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
-  if (stats) {
-    stats->status = rc;
-    stats->mode_used = mode;
-    const bool cert_opts = opts->object_merge_factor > 0.0f &&
-                           (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
-                                                                 : opts->merge_logprob_bias == 0.0f);
-    stats->cert_edge_violations = c->h_scalars[0];
-    stats->cert_class_violations = c->h_scalars[3];
-    stats->cert_record_violations = c->h_scalars[4];
-    stats->certified = (want_cert && c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
-    stats->num_instances = c->h_scalars[1];
-    stats->num_objects = c->h_scalars[2];
-    stats->rounds = rounds;
-    stats->finisher_steps = c->h_cnt->finisher_steps;
-    stats->initial_records = R0;
-    stats->merges = merges;
-    stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
-    stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
-    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
-    if (mode == MN_MODE_COMPONENTS) {
-      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); stats->ms_cc_label = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_edges = ms;
-    }
-  }
-  g_last_status = rc;
+  if (stats) *stats = q.stats;
+  q.active = 0;
   return rc;
 }
 
@@ -775,14 +861,15 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
                                  int num_classes, const int* offset_list, int* d_mask,
                                  int* d_object_class, int* d_partition, const mn_options* opts,
                                  void* stream, mn_stats* stats) {
-  int rc = segment_attempt(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
-                           offset_list, d_mask, d_object_class, d_partition, opts, stream, stats, 0,
-                           true);
-  if (rc == MN_RETRY_ROUNDS || rc == MN_RETRY_WAIT)
-    rc = segment_attempt(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
-                         offset_list, d_mask, d_object_class, d_partition, opts, stream, stats,
-                         rc == MN_RETRY_ROUNDS ? MN_MODE_ROUNDS : 0, false);
-  return rc;
+  int rc = MN_ERR_ARGUMENT;
+  if (!c || !c->pend.active)          // (a context with an unfinished launch is busy)
+    rc = mn_segment_launch(c, d_class_pred, class_dim, d_adj_pred, offset_dim, W, H, num_classes,
+                           offset_list, d_mask, d_object_class, d_partition, opts, stream);
+  if (rc != MN_OK) {                  // rejected, busy or failed: nothing was left pending
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = rc; stats->total_logprob = NAN; }
+    return rc;
+  }
+  return mn_segment_finish(c, stats);
 }
 
 extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int class_dim,

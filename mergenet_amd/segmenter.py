@@ -68,7 +68,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
-           "mn_segment_device", "mn_score_device", "mn_segment_host", "c_run_segmentation",
+           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device",
            "mn_last_status", "mn_status_string", "mn_version"]
@@ -104,6 +104,10 @@ def load_library() -> ctypes.CDLL:
                                       ctypes.c_void_p, ctypes.POINTER(MnOptions), ctypes.c_void_p,
                                       ctypes.POINTER(MnStats)]
     lib.mn_segment_device.restype = ctypes.c_int
+    lib.mn_segment_launch.argtypes = lib.mn_segment_device.argtypes[:-1]
+    lib.mn_segment_launch.restype = ctypes.c_int
+    lib.mn_segment_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(MnStats)]
+    lib.mn_segment_finish.restype = ctypes.c_int
     lib.mn_score_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                     ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
@@ -383,6 +387,31 @@ class Merger:
             raise MergeNetError(rc)
         return mask, table, part, stats.as_dict()
 
+    def segment_async(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None,
+                      want_partition: bool = False) -> "PendingSegment":
+        """Queue one image (``mn_segment_launch``) and return at once; ``.result()`` of the returned
+        object waits and gives what :meth:`segment` gives.  The Merger is busy until then -- use
+        two of them alternately on one stream to keep the GPU busy across images: the launch of
+        image i+1 then precedes the read-back of image i, and kernels of different images still
+        do not overlap (their timings stay clean)."""
+        torch = self.torch
+        C, H, W, O, off = self._check(class_probs, same_probs, offsets)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs.device
+        mask = torch.empty((H, W), dtype=torch.int32, device=dev)
+        table = torch.empty((H * W,), dtype=torch.int32, device=dev)
+        part = torch.empty((H, W), dtype=torch.int32, device=dev) if want_partition else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_segment_launch(self.handle, class_probs.data_ptr(), C,
+                                        same_probs.data_ptr(), O, W, H, C,
+                                        off.ctypes.data_as(_i32p), mask.data_ptr(),
+                                        table.data_ptr(),
+                                        part.data_ptr() if part is not None else None,
+                                        ctypes.byref(opts), ctypes.c_void_p(stream))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return PendingSegment(self, mask, table, part, (class_probs, same_probs, opts))
+
     def score(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None,
               want_arrays: bool = False):
         """Phase A only.  Returns (ms_class_pass, ms_edge_pass[, cls uint8[H,W], best int64[H,W]])."""
@@ -495,6 +524,24 @@ class Merger:
         if rc != 0:
             raise MergeNetError(rc)
         return out[:num_instances]
+
+
+class PendingSegment:
+    """An image queued by :meth:`Merger.segment_async`; ``result()`` finishes it (once)."""
+
+    def __init__(self, merger, mask, table, part, keepalive):
+        self._merger, self._out, self._keepalive = merger, (mask, table, part), keepalive
+        self._done = None
+
+    def result(self):
+        if self._done is None:
+            stats = MnStats()
+            rc = self._merger.lib.mn_segment_finish(self._merger.handle, ctypes.byref(stats))
+            self._keepalive = None
+            if rc != 0:
+                raise MergeNetError(rc)
+            self._done = self._out + (stats.as_dict(),)
+        return self._done
 
 
 class MergerPool:

@@ -194,3 +194,39 @@ def test_merger_pool_equals_serial_merger_and_keeps_order():
     single.close()
     with pytest.raises(RuntimeError):
         pool.submit(images[0][0], images[0][1], offs, opts)
+
+
+def test_segment_async_two_contexts_one_stream_equals_segment():
+    """mn_segment_launch / mn_segment_finish: launches of image i+1 ahead of the read-back of
+    image i give the results of the blocking call, in every mode (fallbacks included)."""
+    import torch
+    from mergenet_amd import segmenter as seg, synth
+    offs = synth.generate_offsets(12, 6)
+    H, W, C = 96, 160, 4
+    cases = []
+    for seed, noise in [(700, 0.15), (701, 0.45), (702, 0.15), (703, 0.15)]:     # 0.45: falls back
+        s = synth.synth_v1(H, W, C, offs, seed, noise=noise)
+        cases.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
+    a, b = seg.Merger(H, W, C, len(offs)), seg.Merger(H, W, C, len(offs))
+    for mode in (seg.MN_MODE_COMPONENTS, seg.MN_MODE_ROUNDS, seg.MN_MODE_AUTO):
+        opts = seg.default_options(mode=mode, clip_inputs=1)
+        want = [a.segment(cp, sp, offs, opts) for cp, sp in cases]
+        got, prev = [], None
+        for i, (cp, sp) in enumerate(cases):
+            cur = (a, b)[i % 2].segment_async(cp, sp, offs, opts)
+            if prev is not None:
+                got.append(prev.result())
+            prev = cur
+        got.append(prev.result())
+        for (m, t, _, st), (wm, wt, _, wst) in zip(got, want):
+            assert torch.equal(m, wm) and st["num_instances"] == wst["num_instances"]
+            assert st["mode_used"] == wst["mode_used"] and st["total_logprob"] == wst["total_logprob"]
+            assert torch.equal(t[: st["num_instances"]], wt[: wst["num_instances"]])
+    # a busy context refuses a second launch and the blocking call
+    p = a.segment_async(cases[0][0], cases[0][1], offs, opts)
+    with pytest.raises(seg.MergeNetError):
+        a.segment_async(cases[1][0], cases[1][1], offs, opts)
+    with pytest.raises(seg.MergeNetError):
+        a.segment(cases[1][0], cases[1][1], offs, opts)
+    assert p.result()[3]["num_instances"] == want[0][3]["num_instances"]
+    a.close(); b.close()
