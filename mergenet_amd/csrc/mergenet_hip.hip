@@ -511,7 +511,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
-  if (c->h_scalars[6] != 0) {
+  if (c->h_scalars[6] != 0 || c->h_scalars[7] != 0) {     // not separable, or the table filled up
     MN_HIP(hipMemsetAsync(c->cnt, 0, sizeof(Counters), st));
     return 1;
   }
@@ -534,7 +534,7 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
                              mn_stats* stats) {
   if (speculate) {
     if (c->h_scalars[6] != 0) return MN_RETRY_ROUNDS;
-    if (c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
+    if (c->h_scalars[7] != 0 || c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
   }
   const long long merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
   const int rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
@@ -617,11 +617,14 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   fills.add(c->cnt, sizeof(Counters), 0);
   fills.add(c->scalars, 8 * sizeof(int), 0);
   fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);
+  speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
   if (mode == MN_MODE_COMPONENTS) {
-    // everything the contraction and the compaction after it expect cleared, in the same launch
-    // records between components are few; a table that turns out too small fails the bounded
-    // insert, which counts as "not separable" and sends the image to the rounds
-    size_t cap = next_pow2((size_t)N / 8 + 8192);
+    // everything the contraction and the compaction after it expect cleared, in the same launch.
+    // Records between components are few: the speculative attempt, which only stands with at
+    // most finish_limit of them, takes a table of 8x that many slots (less to clear, less for
+    // mn_compact to scan); the ordinary attempt one of N/8.  A table that fills up fails the
+    // bounded insert, counted apart from the separability violations (scalars[7]).
+    size_t cap = speculate ? next_pow2((size_t)finish_limit * 8) : next_pow2((size_t)N / 8 + 8192);
     if (cap > c->cc_cap_max) cap = c->cc_cap_max;
     c->cc_cap = cap;
     fills.add(c->T.key, cap * sizeof(u64), 0xFF);
@@ -638,7 +641,6 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // ---------------- phase A ----------------
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
-  speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
   if (mode == MN_MODE_COMPONENTS) {
     rc = run_components(c, P, st, !speculate);
     if (rc < 0) return rc;

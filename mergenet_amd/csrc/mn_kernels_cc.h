@@ -434,7 +434,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, O
   const int tile = mn_xcd_tile((P.N + MN_CC_EDGE_THREADS - 1) / MN_CC_EDGE_THREADS, P.banded);
   const int p = tile < 0 ? P.N : tile * MN_CC_EDGE_THREADS + threadIdx.x;
   const bool live = p < P.N;
-  int bad = 0;
+  int bad = 0, over = 0;
   const int root = live ? S.parent[p] : 0;
   if (live && cls0[p] != cls0[root]) bad++;                          // (c) one class per component
   const int r = live ? p / P.W : 0, c0 = live ? p - r * P.W : 0;
@@ -475,17 +475,18 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, O
       const u64 key = mn_key(root, rq[j]);
       const i64 s = mn_edge_fixed(x);
       if (key == ckey) { csum += s; continue; }
-      if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+      if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) over++;
       ckey = key;
       csum = s;
     }
   }
-  if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) bad++;
+  if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) over++;
   __syncthreads();
   if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
-    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x])) bad++;
+    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x])) over++;
   for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
+  if (over) atomicAdd(violations + 1, over);   // table full: not a verdict on the maps
 }
 
 // The same sweep with 4 consecutive pixels of one row per lane (W % 4 == 0): the sameness values
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
   const int i = blockIdx.x * MN_CC_EDGE_THREADS + threadIdx.x;
   const bool live = i < n4;
   const int p0 = live ? 4 * i : 0;
-  int bad = 0;
+  int bad = 0, over = 0;
   const int r = p0 / P.W, c0 = p0 - r * P.W;
   int root0 = 0, root1 = 0, root2 = 0, root3 = 0;
   if (live) {
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
       t_diff += (double)ld;
       const i64 sx = __float2ll_rn((logf(x) - ld) * (float)MN_FIX_ONE);   // = mn_edge_fixed(x)
       if (key == ckey) { csum += sx; ccnt++; return; }
-      if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) bad++;
+      if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) over++;
       ckey = key;
       csum = sx;
       ccnt = 1;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
       edge(first[j] + 3, v[j].w, rq[j].w, root3);
     }
   }
-  if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) bad++;
+  if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) over++;
   for (int off = 32; off > 0; off >>= 1) {
     bad += __shfl_xor(bad, off);
     t_same += __shfl_xor(t_same, off);
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, 
   if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
     if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x], tcount, s_cnt[threadIdx.x]))
       late = 1;
-  if (late) atomicAdd(violations, 1);
+  if (late || over) atomicAdd(violations + 1, late + over);   // table full: not a verdict on the maps
   if (threadIdx.x < 2) {                                // block order: the sum is reproducible
     double t = 0.0;
     for (int w = 0; w < MN_CC_EDGE_THREADS / 64; w++) t += s_part[threadIdx.x][w];

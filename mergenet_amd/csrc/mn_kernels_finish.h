@@ -229,7 +229,7 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     const int* __restrict__ spec_violations, int spec_limit, int* __restrict__ lcount) {
   if (spec_records) {
     R = *spec_records;
-    if (R > spec_limit || *spec_violations != 0) return;          // uniform
+    if (R > spec_limit || spec_violations[0] != 0 || spec_violations[1] != 0) return;   // uniform
   }
   // One CU runs this loop, and what bounds a step is instruction issue (16 waves share 4 SIMDs),
   // so the per-record work of the two scans is kept to a couple of instructions: the queue is an
