@@ -10,7 +10,7 @@ for name in sys.argv[1:]:
     ctx = seg.HostContext(H, W, C, len(g["offsets"]))
     for mode in (seg.MN_MODE_COMPONENTS, seg.MN_MODE_ROUNDS):
         sdb, omf, bias = g["spec"]["opts"]
-        o = seg.default_options(mode=mode, same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias, clip_inputs=1)
+        o = seg.default_options(mode=mode, same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias, clip_inputs=1, finish_limit=int(__import__("os").environ.get("MN_FINISH", "0")))
         for rep in range(2):
             mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         eq = labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])

@@ -17,6 +17,7 @@ MODE = int(sys.argv[7]) if len(sys.argv) > 7 else 0            # 0 AUTO, 2 ROUND
 import os
 INSTANCES = int(os.environ["MN_CAMPAIGN_INSTANCES"]) if "MN_CAMPAIGN_INSTANCES" in os.environ else None
 BIAS = float(os.environ.get("MN_CAMPAIGN_BIAS", "0.03"))       # merge_logprob_bias (csegment variant)
+FINISH = int(os.environ.get("MN_CAMPAIGN_FINISH", "0"))        # finish_limit (0 = library default)
 
 
 def oracle_one(seed):
@@ -45,7 +46,7 @@ if __name__ == "__main__":
                 o = seg.default_options(mode=MODE, variant=seg.MN_VARIANT_PYSEGMENTER,
                                         object_merge_factor=1.0 / len(offs), merge_logprob_bias=0.0)
             else:
-                o = seg.default_options(mode=MODE, merge_logprob_bias=BIAS)
+                o = seg.default_options(mode=MODE, merge_logprob_bias=BIAS, finish_limit=FINISH)
             mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
             gpu[seed] = (mask, classes, st)
         while not pending.ready():
@@ -60,4 +61,4 @@ if __name__ == "__main__":
         print("seed %d: %s  mode_used %d  instances gpu %d ref %d  certified %d  gpu %.1f ms  oracle %.0f s  rel.loglik diff %.1e"
               % (seed, "EQUAL" if ok else "DIFFERENT", st["mode_used"], len(classes), len(rcls), st["certified"], st["ms_total"], dt,
                  abs(st["total_logprob"] - rlp) / abs(rlp)), flush=True)
-    print("parity campaign %s mode %d %dx%d noise %.2f instances %s bias %.3f: %d/%d images identical to the sequential reference order" % (VARIANT, MODE, H, W, NOISE, INSTANCES, BIAS, eq, len(SEEDS)))
+    print("parity campaign %s mode %d %dx%d noise %.2f instances %s bias %.3f finish_limit %d: %d/%d images identical to the sequential reference order" % (VARIANT, MODE, H, W, NOISE, INSTANCES, BIAS, FINISH, eq, len(SEEDS)))
