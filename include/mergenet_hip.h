@@ -40,7 +40,9 @@ enum mn_status {
   MN_ERR_NO_DEVICE = -3,    /* no usable HIP device / HIP call failed (message on stderr)     */
   MN_ERR_CAPACITY = -4,     /* image larger than the context was created for                  */
   MN_ERR_NO_BACKGROUND = -10, /* pysegmenter prune: no class-0 object (reference: NameError)  */
-  MN_ERR_INTERNAL = -20
+  MN_ERR_INTERNAL = -20,
+  MN_ERR_UNPROVEN = -30     /* require_proof set and the result is neither certified nor from the
+                               sequential order (the approximate result IS written)              */
 };
 
 enum mn_variant {
@@ -77,7 +79,12 @@ typedef struct mn_options {
   int band_permille;           /* ROUNDS: a round merges only records whose gain is >= this many
                                   thousandths of the round's best gain (0 = default 100, <0 = off;
                                   parity with the reference was lost at 10, once in 65 runs at 25, never from 50 up)   */
-  int reserved[2];
+  int debug_flags;             /* bit 0: use the generic edge pass where the fast form would run (tests
+                                  compare the two); 0 in production                                */
+  int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
+                                  order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
+                                  has at most exact_limit_proof initial records, else the call returns
+                                  MN_ERR_UNPROVEN -- the library says no instead of guessing       */
 } mn_options;
 
 typedef struct mn_stats {
@@ -106,6 +113,12 @@ typedef struct mn_stats {
   float ms_cc_sums;            /* mn_cc_sums: reads the C class planes                                  */
   float ms_cc_edges;           /* mn_cc_edges: reads the O sameness planes                              */
   float ms_reserved;
+  int proof;                   /* why the partition equals the reference's: 0 = not proven (measured
+                                  only; an approximation of the sequential order on order-dependent
+                                  inputs), 1 = certificate (ANY order of the lazy greedy ends here,
+                                  DESIGN.md section 5), 2 = the sequential order itself was run
+                                  (MN_MODE_EXACT; ties between bit-equal priorities aside)         */
+  int reserved_i[3];
 } mn_stats;
 
 typedef struct mn_context mn_context;

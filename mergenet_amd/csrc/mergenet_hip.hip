@@ -42,6 +42,7 @@ struct mn_context {
   int maxH, maxW, maxC, maxO;
   size_t N, Rmax, cap;
   size_t cc_cap;          // table capacity used by the last component contraction
+  int debug_flags;        // mn_options.debug_flags of the call in progress
   size_t bytes;
   // objects
   unsigned char *ocls, *cls0, *lpvalid, *matched, *pruned;
@@ -138,6 +139,7 @@ extern "C" const char* mn_status_string(int s) {
     case MN_ERR_CAPACITY: return "image exceeds the context's capacity";
     case MN_ERR_NO_BACKGROUND: return "prune: no class-0 object to merge into";
     case MN_ERR_INTERNAL: return "internal error";
+    case MN_ERR_UNPROVEN: return "result not proven equal to the reference's sequential order (require_proof)";
     default: return "unknown status";
   }
 }
@@ -357,7 +359,7 @@ static void launch_edge_pass(mn_context* c, const ImgParams& P, hipStream_t st, 
   const dim3 gx(8 * ((grid_for(P.N, 256) + 7) / 8));
   const unsigned char* cls0 = c->ocls;       // unchanged until mn_pix_apply
   const unsigned char* matched = c->matched;
-  const bool fast = P.omf > 0.0f && P.sdb == 0.0f;
+  const bool fast = P.omf > 0.0f && P.sdb == 0.0f && !(c->debug_flags & 1);
   if (fast && P.O == 10 && !P.clip)
     hipLaunchKernelGGL((mn_edge_pass_fast<10, FIRST, false>), gx, b, 0, st, P, cls0, matched, out,
                        progress, s);
@@ -548,6 +550,7 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->cert_class_violations = c->h_scalars[3];
     stats->cert_record_violations = c->h_scalars[4];
     stats->certified = (want_cert && c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
+    stats->proof = stats->certified ? 1 : (mode == MN_MODE_EXACT ? 2 : 0);
     stats->num_instances = c->h_scalars[1];
     stats->num_objects = c->h_scalars[2];
     stats->rounds = rounds;
@@ -591,6 +594,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
 
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  c->debug_flags = opts->debug_flags;
   const int N = P.N;
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
@@ -660,11 +664,11 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     // round 0 on the implicit pixel graph: matching sub-rounds, then one apply
     MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
     hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                       (const u64*)c->ball, c->matched, c->mate, c->progress, 0);
+                       (const u64*)c->ball, c->matched, c->mate, c->progress, 0, c->cnt);
     for (int s = 1; s < subrounds; s++) {
       launch_edge_pass<false>(c, P, st, c->bsub, s);
       hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                         (const u64*)c->bsub, c->matched, c->mate, c->progress, s);
+                         (const u64*)c->bsub, c->matched, c->mate, c->progress, s, c->cnt);
     }
     hipLaunchKernelGGL(mn_pix_apply, dim3(grid_for(N, 256)), dim3(256), 0, st, P, S,
                        (const int*)c->mate, c->cnt);
@@ -689,16 +693,16 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                          P.bias, P.variant, band_gamma, c->theta);
       MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
-                         (const float*)c->theta, c->matched, c->mate, c->progress);
+                         (const float*)c->theta, c->matched, c->mate, c->progress, c->cnt);
       MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));   // accept cleans up after
       // late rounds are launch-bound: fewer matching sub-rounds once the list is small
       const int sub_r = R > (1 << 20) ? subrounds : (subrounds > 8 ? subrounds / 4 : subrounds);
       for (int s = 1; s < sub_r; s++) {
         hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
                            (const float*)c->theta, (const unsigned char*)c->matched, c->bsub,
-                           (const int*)c->progress, s);
+                           (const int*)c->progress, s, c->cnt);
         hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate,
-                           c->progress, s);
+                           c->progress, s, c->cnt);
       }
       hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const int*)c->mate, c->cnt);
       size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);   // load <= 2/3
@@ -853,6 +857,18 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
                            q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
                            rc == MN_RETRY_ROUNDS ? MN_MODE_ROUNDS : 0, false);
   }
+  // require_proof: a result that is only an approximation of the reference's order is redone in
+  // the sequential order when that is affordable, otherwise the caller is told
+  if (rc == MN_OK && q.opts.require_proof && q.stats.proof == 0) {
+    const long long lim = q.opts.exact_limit > 0 ? q.opts.exact_limit : 32768;
+    if (q.stats.initial_records <= 8 * lim)
+      rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
+                           q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
+                           MN_MODE_EXACT, false);
+    else
+      rc = MN_ERR_UNPROVEN;
+    if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
+  }
   if (stats) *stats = q.stats;
   q.active = 0;
   return rc;
@@ -889,6 +905,7 @@ extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int cla
   hipStream_t st = static_cast<hipStream_t>(stream);
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  c->debug_flags = opts->debug_flags;
   rc = run_phase_a(c, P, st, true);
   if (rc != MN_OK) return rc;
   if (d_cls_out) MN_HIP(hipMemcpyAsync(d_cls_out, c->ocls, P.N, hipMemcpyDeviceToDevice, st));
@@ -932,7 +949,7 @@ extern "C" int mn_segment_host(mn_context* c, const float* class_pred, int class
   MN_HIP(hipMemcpy(c->d_same, adj_pred, N * offset_dim * sizeof(float), hipMemcpyHostToDevice));
   rc = mn_segment_device(c, c->d_class, num_classes, c->d_same, offset_dim, W, H, num_classes,
                          offset_list, c->d_mask, c->d_objcls, c->d_part, opts, NULL, stats);
-  if (rc != MN_OK && rc != MN_ERR_NO_BACKGROUND) return rc;
+  if (rc != MN_OK && rc != MN_ERR_NO_BACKGROUND && rc != MN_ERR_UNPROVEN) return rc;
   MN_HIP(hipMemcpy(mask, c->d_mask, N * sizeof(int), hipMemcpyDeviceToHost));
   MN_HIP(hipMemcpy(object_class, c->d_objcls, N * sizeof(int), hipMemcpyDeviceToHost));
   if (partition) MN_HIP(hipMemcpy(partition, c->d_part, N * sizeof(int), hipMemcpyDeviceToHost));

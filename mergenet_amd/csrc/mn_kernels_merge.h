@@ -98,13 +98,15 @@ __global__ __launch_bounds__(256) void mn_init_objects(int N, int* __restrict__ 
 __global__ __launch_bounds__(256) void mn_pix_match(int N, const u64* __restrict__ best,
                                                     unsigned char* __restrict__ matched,
                                                     int* __restrict__ mate,
-                                                    int* __restrict__ progress, int s) {
+                                                    int* __restrict__ progress, int s,
+                                                    Counters* __restrict__ cnt) {
   if (s > 0 && !progress[s - 1]) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
   const u64 b = best[p];
   if (b == 0) return;
   const int q = mn_pack_partner(b);
+  if ((unsigned)q >= (unsigned)N) { cnt->error = MN_ERR_INTERNAL; return; }   // stale slot: counted, not followed
   const u64 bq = best[q];
   if (bq == 0 || mn_pack_partner(bq) != p) return;
   matched[p] = 1;
@@ -270,12 +272,16 @@ __global__ __launch_bounds__(256) void mn_obj_match_mutual(int N, const u64* __r
                                                            const float* __restrict__ theta,
                                                            unsigned char* __restrict__ matched,
                                                            int* __restrict__ mate,
-                                                           int* __restrict__ progress) {
+                                                           int* __restrict__ progress,
+                                                           Counters* __restrict__ cnt) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   const u64 b = ball[u];
   if (b == 0 || !mn_in_band(b, *theta)) return;
   const int t = mn_pack_partner(b);
+  // a partner id decoded from a slot nobody wrote this round would be a wild read (the round-1
+  // fault): counted as an internal error instead of followed
+  if ((unsigned)t >= (unsigned)N) { cnt->error = MN_ERR_INTERNAL; return; }
   const u64 bt = ball[t];
   if (bt == 0 || mn_pack_partner(bt) != u) return;
   matched[u] = 1;
@@ -287,23 +293,29 @@ __global__ __launch_bounds__(256) void mn_obj_propose(int N, const u64* __restri
                                                       const float* __restrict__ theta,
                                                       const unsigned char* __restrict__ matched,
                                                       u64* __restrict__ inbest,
-                                                      const int* __restrict__ progress, int s) {
+                                                      const int* __restrict__ progress, int s,
+                                                      Counters* __restrict__ cnt) {
   if (!progress[s - 1]) return;        // the previous sub-round paired nothing: nothing can change
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N || matched[u]) return;
   const u64 b = ball[u];
   if (b == 0 || !mn_pack_gain_pos(b) || !mn_in_band(b, *theta)) return;
   const int t = mn_pack_partner(b);
+  if ((unsigned)t >= (unsigned)N) { cnt->error = MN_ERR_INTERNAL; return; }
   if (matched[t]) return;
   const u64 bt = ball[t];
-  if (bt == 0 || !matched[mn_pack_partner(bt)]) return;     // t still waits for its own choice
+  if (bt == 0) return;
+  const int tt = mn_pack_partner(bt);
+  if ((unsigned)tt >= (unsigned)N) { cnt->error = MN_ERR_INTERNAL; return; }
+  if (!matched[tt]) return;            // t still waits for its own choice
   atomicMax(&inbest[t], (b & 0xFFFFFFFF00000000ull) | (u64)(0x7FFFFFFFu - (unsigned)u));
 }
 
 __global__ __launch_bounds__(256) void mn_obj_accept(int N, u64* __restrict__ inbest,
                                                      unsigned char* __restrict__ matched,
                                                      int* __restrict__ mate,
-                                                     int* __restrict__ progress, int s) {
+                                                     int* __restrict__ progress, int s,
+                                                     Counters* __restrict__ cnt) {
   if (!progress[s - 1]) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256) void mn_obj_accept(int N, u64* __restrict__ in
   inbest[t] = 0;                       // self-cleaning: no memset between sub-rounds
   if (matched[t]) return;
   const int u = mn_pack_partner(k);
+  if ((unsigned)u >= (unsigned)N) { cnt->error = MN_ERR_INTERNAL; return; }
   matched[t] = 1; mate[t] = u;
   matched[u] = 1; mate[u] = t;
   progress[s] = 1;

@@ -30,6 +30,8 @@ MN_VARIANT_CSEGMENT = 0
 MN_VARIANT_PYSEGMENTER = 1
 MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS, MN_MODE_COMPONENTS = 0, 1, 2, 3
 MN_ERR_NO_BACKGROUND = -10
+MN_ERR_UNPROVEN = -30
+MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
 
 SegmenterOptions = namedtuple("SegmenterOptions",
                               ["same_different_bias", "object_merge_factor", "merge_logprob_bias"])
@@ -42,7 +44,8 @@ class MnOptions(ctypes.Structure):
                 ("exact_limit", ctypes.c_int), ("finish_limit", ctypes.c_int),
                 ("subrounds", ctypes.c_int), ("prune_threshold", ctypes.c_float),
                 ("compute_logprob", ctypes.c_int), ("no_handover_refresh", ctypes.c_int),
-                ("band_permille", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
+                ("band_permille", ctypes.c_int), ("debug_flags", ctypes.c_int),
+                ("require_proof", ctypes.c_int)]
 
 
 class MnStats(ctypes.Structure):
@@ -57,10 +60,11 @@ class MnStats(ctypes.Structure):
                 ("ms_edge_pass", ctypes.c_float), ("ms_merge", ctypes.c_float),
                 ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
-                ("ms_cc_edges", ctypes.c_float), ("ms_reserved", ctypes.c_float)]
+                ("ms_cc_edges", ctypes.c_float), ("ms_reserved", ctypes.c_float),
+                ("proof", ctypes.c_int), ("reserved_i", ctypes.c_int * 3)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}
 
 
 _f32p = ctypes.POINTER(ctypes.c_float)

@@ -200,3 +200,57 @@ def adversarial(H: int, W: int, num_classes: int, offsets: Sequence[Tuple[int, i
 def count_edges(H: int, W: int, offsets: Sequence[Tuple[int, int]]) -> int:
     """Number of in-bounds (pixel, offset) pairs = initial adjacency records."""
     return sum(max(0, H - abs(i)) * max(0, W - abs(j)) for (i, j) in offsets)
+
+
+def _box_blur(a: np.ndarray, r: int) -> np.ndarray:
+    """Mean over a (2r+1)^2 window, edges replicated; ``a`` is [K, H, W]."""
+    if r == 0:
+        return a
+    p = np.pad(a, ((0, 0), (r, r), (r, r)), mode="edge").astype(np.float64)
+    cs = p.cumsum(1).cumsum(2)
+    cs = np.pad(cs, ((0, 0), (1, 0), (1, 0)))
+    k = 2 * r + 1
+    s = cs[:, k:, k:] - cs[:, :-k, k:] - cs[:, k:, :-k] + cs[:, :-k, :-k]
+    return (s / (k * k)).astype(np.float32)
+
+
+def blurred_v1(H: int, W: int, num_classes: int, offsets: Sequence[Tuple[int, int]], seed: int,
+               radius: int = 2, noise: float = 0.05,
+               num_instances: int | None = None) -> SynthImage:
+    """Network-like maps: the noise-free synth-v1 maps box-blurred (certainty fades towards the
+    instance boundaries and passes through 0.5 next to them), then the synth-v1 noise added.
+    Such maps are NOT sign-separable; the reference's result on them depends on its sequential
+    order."""
+    clean = synth_v1(H, W, num_classes, offsets, seed, noise=0.0, num_instances=num_instances)
+    noisy = synth_v1(H, W, num_classes, offsets, seed, noise=noise, num_instances=num_instances)
+    cp = _box_blur(clean.class_probs, radius) + (noisy.class_probs - clean.class_probs)
+    sp = _box_blur(clean.sameness_probs, radius) + (noisy.sameness_probs - clean.sameness_probs)
+    cp = np.clip(cp, 0.01, 0.99).astype(np.float32)
+    sp = np.clip(sp, 0.01, 0.99).astype(np.float32)
+    return SynthImage(cp, sp, clean.instances, clean.instance_class, list(clean.offsets), seed,
+                      dict(H=H, W=W, C=num_classes, noise=noise, radius=radius, blurred=True))
+
+
+def checkerboard(H: int, W: int, num_classes: int, offsets: Sequence[Tuple[int, int]],
+                 cell_px: int, seed: int) -> SynthImage:
+    """Cells of ``cell_px`` pixels with a random class each: hundreds of small components whose
+    further merging is driven by ``merge_logprob_bias`` alone (bias-dominated second phase)."""
+    offsets = [(int(i), int(j)) for (i, j) in offsets]
+    validate_offsets(offsets)
+    rng = np.random.default_rng(seed)
+    cell = (np.arange(H)[:, None] // cell_px) * ((W + cell_px - 1) // cell_px) + \
+        (np.arange(W)[None, :] // cell_px)
+    cmap = rng.integers(0, num_classes, size=cell.max() + 1)[cell]
+    cp = np.full((num_classes, H, W), 0.05, np.float32)
+    for c in range(num_classes):
+        cp[c][cmap == c] = 0.9
+    cp += rng.uniform(0, 0.01, size=cp.shape).astype(np.float32)
+    sp = np.zeros((len(offsets), H, W), np.float32)
+    for k, (di, dj) in enumerate(offsets):
+        other = np.full((H, W), -1)
+        r0, r1 = max(0, -di), min(H, H - di)
+        c0, c1 = max(0, -dj), min(W, W - dj)
+        other[r0:r1, c0:c1] = cell[r0 + di:r1 + di, c0 + dj:c1 + dj]
+        sp[k] = np.where(other == cell, 0.9, 0.1) + rng.uniform(-0.05, 0.05, size=(H, W))
+    return SynthImage(cp.astype(np.float32), sp.astype(np.float32), cell.astype(np.int32), [0],
+                      list(offsets), seed, dict(H=H, W=W, C=num_classes, checkerboard=cell_px))

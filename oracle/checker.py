@@ -121,6 +121,60 @@ def run_csegment(class_probs, same_probs, num_classes: int, offsets: Sequence[Tu
                         dict(zip(names, stats.tolist())))
 
 
+def phase_a(class_probs, same_probs, num_classes: int, offsets: Sequence[Tuple[int, int]],
+            same_different_bias: float = 0.0, object_merge_factor: float = 1.0,
+            merge_logprob_bias: float = 0.0):
+    """Phase A of the reference constructor (segment.cc:5-46,107-150,198-231): returns
+    (cls int32[H,W], oml float32[O,H,W], prio float32[O,H,W]); NaN where the edge leaves the image."""
+    lib = _load("libcsegment_oracle.so")
+    fn = lib.oracle_csegment_phase_a
+    fn.restype = ctypes.c_int
+    fn.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_int, _i32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32p,
+                   _f32p, _f32p]
+    cp, sp, off = _prep(class_probs, same_probs, offsets)
+    C, H, W = cp.shape
+    O = sp.shape[0]
+    cls = np.zeros((H, W), np.int32)
+    oml = np.zeros((O, H, W), np.float32)
+    prio = np.zeros((O, H, W), np.float32)
+    rc = fn(cp.ctypes.data_as(_f32p), C, sp.ctypes.data_as(_f32p), O, W, H, int(num_classes),
+            off.ctypes.data_as(_i32p), float(same_different_bias), float(object_merge_factor),
+            float(merge_logprob_bias), cls.ctypes.data_as(_i32p), oml.ctypes.data_as(_f32p),
+            prio.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise ValueError("oracle_csegment_phase_a rejected its arguments (code %d)" % rc)
+    return cls, oml, prio
+
+
+def best_initial_record(prio: np.ndarray, offsets) -> Tuple[np.ndarray, np.ndarray]:
+    """Per pixel the best incident initial record with priority >= 0: (priority float32[H,W],
+    partner pixel id int64[H,W]; -1 / NaN where the pixel has none).  Outgoing edge k of p is
+    prio[k, p]; the incoming one is prio[k, p - o_k].  Ties: lowest partner id."""
+    O, H, W = prio.shape
+    best = np.full((H, W), -np.inf, np.float64)
+    partner = np.full((H, W), -1, np.int64)
+    ids = np.arange(H * W, dtype=np.int64).reshape(H, W)
+
+    def consider(pr, q, r0, r1, c0, c1):
+        cur_b, cur_p = best[r0:r1, c0:c1], partner[r0:r1, c0:c1]
+        ok = ~np.isnan(pr) & (pr >= 0)
+        better = ok & ((pr > cur_b) | ((pr == cur_b) & (q < cur_p)))
+        cur_b[better] = pr[better]
+        cur_p[better] = q[better]
+
+    for k, (di, dj) in enumerate(offsets):
+        r0, r1 = max(0, -di), min(H, H - di)
+        c0, c1 = max(0, -dj), min(W, W - dj)
+        if r0 >= r1 or c0 >= c1:
+            continue
+        src = prio[k, r0:r1, c0:c1].astype(np.float64)
+        consider(src, ids[r0 + di:r1 + di, c0 + dj:c1 + dj], r0, r1, c0, c1)          # outgoing
+        consider(src, ids[r0:r1, c0:c1], r0 + di, r1 + di, c0 + dj, c1 + dj)          # incoming
+    out = np.where(partner >= 0, best, np.nan).astype(np.float32)
+    return out, partner
+
+
 def run_reference(class_probs, same_probs, num_classes: int, offsets: Sequence[Tuple[int, int]],
                   same_different_bias: float = 0.0, object_merge_factor: float = 1.0,
                   merge_logprob_bias: float = 0.0) -> OracleResult:

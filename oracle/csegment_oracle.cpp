@@ -332,4 +332,67 @@ int oracle_csegment_run(float* class_pred, int class_dim, float* adj_pred, int o
   return 0;
 }
 
+
+// Phase A alone (the reference constructor, segment.cc:153-232): per-pixel arg-max class
+// (Object::Object, :5-21), per in-bounds (pixel, offset) record its log-odds
+// obj_merge_logprob (AdjacencyRecord ctor, :24-46) and its initial merge priority
+// (ComputeClassDeltaLogprob + UpdateMergePriority, :107-150), in creation order (row-major
+// pixels, offsets in list order, :209-231).  cls_out[N]; oml_out / prio_out [O][N] indexed by
+// the SOURCE pixel, NaN where the edge leaves the image.  adj_pred is rewritten in place when
+// same_different_bias != 0, as by the reference (:183-195).
+int oracle_csegment_phase_a(float* class_pred, int class_dim, float* adj_pred, int offset_dim,
+                            int img_width, int img_height, int num_classes,
+                            const int* offset_list, float same_different_bias,
+                            float object_merge_factor, float merge_logprob_bias, int* cls_out,
+                            float* oml_out, float* prio_out) {
+  if (!class_pred || !adj_pred || !offset_list || !cls_out || !oml_out || !prio_out) return -1;
+  if (img_width <= 0 || img_height <= 0 || num_classes <= 0 || offset_dim < 0) return -2;
+  if (class_dim < num_classes) return -3;
+  const int C = num_classes, O = offset_dim, W = img_width, H = img_height, N = W * H;
+  if (same_different_bias != 0) {
+    for (size_t i = 0; i < (size_t)O * N; i++) {
+      float logit = logf(adj_pred[i]) - log(1.0 - adj_pred[i]) + same_different_bias;
+      adj_pred[i] = 1.0 / (1.0 + expf(-logit));
+    }
+  }
+  std::vector<float> lp((size_t)N * C);
+  for (int p = 0; p < N; p++) {
+    float* l = &lp[(size_t)p * C];
+    int best = 0;
+    for (int c = 0; c < C; c++) {
+      l[c] = logf(class_pred[(size_t)c * N + p]);
+      if (l[c] > l[best]) best = c;
+    }
+    cls_out[p] = best;
+  }
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  for (int k = 0; k < O; k++)
+    for (int row = 0; row < H; row++)
+      for (int col = 0; col < W; col++) {
+        const int p = row * W + col;
+        const int rr = row + offset_list[2 * k], cc = col + offset_list[2 * k + 1];
+        const size_t e = (size_t)k * N + p;
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) { oml_out[e] = nan; prio_out[e] = nan; continue; }
+        const int q = rr * W + cc;
+        const float sp = adj_pred[e];
+        const float diff = (float)log(1.0 - sp);
+        const float same = logf(sp);
+        const float oml = same - diff;
+        // record endpoints ordered by id (SortAndUpdateHash, segment.cc:49-56)
+        const int a = p < q ? p : q, b = p < q ? q : p;
+        float cdl = 0;
+        if (cls_out[a] != cls_out[b]) {
+          const float* la = &lp[(size_t)a * C];
+          const float* lb = &lp[(size_t)b * C];
+          float bestv = la[0] + lb[0];
+          for (int c = 1; c < C; c++) { const float v = la[c] + lb[c]; if (v > bestv) bestv = v; }
+          cdl = bestv - la[cls_out[a]] - lb[cls_out[b]];
+        }
+        const size_t den = 2;
+        oml_out[e] = oml;
+        prio_out[e] = (oml * object_merge_factor + cdl) / den + merge_logprob_bias;
+      }
+  return 0;
+}
+
 }  // extern "C"

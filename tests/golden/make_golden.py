@@ -53,6 +53,13 @@ def make_inputs(spec: dict):
     if kind == "adversarial":
         s = synth.adversarial(H, W, C, offs, spec["seed"])
         return s.class_probs, s.sameness_probs, offs
+    if kind == "blur":
+        s = synth.blurred_v1(H, W, C, offs, spec["seed"], radius=spec["radius"], noise=spec["noise"],
+                             num_instances=spec.get("num_instances"))
+        return s.class_probs, s.sameness_probs, offs
+    if kind == "checker":
+        s = synth.checkerboard(H, W, C, offs, spec["cell_px"], spec["seed"])
+        return s.class_probs, s.sameness_probs, offs
     if kind == "closed_form":
         return closed_form(spec["layout"], H, W, C, offs) + (offs,)
     raise ValueError(kind)
@@ -116,6 +123,21 @@ def cseg_specs(big: bool):
                           offsets=[10, 6], seed=0, opts=(0.0, 1.0, 0.03)))
     specs.append(dict(name="cseg_synth_128x256", kind="synth", H=128, W=256, C=9, offsets=[40, 10],
                       seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))
+    # order-dependent inputs (round 2): maps whose certainty fades at the instance boundaries
+    # (blurred), images crowded with 48 overlapping instances, a bias-dominated checkerboard
+    specs.append(dict(name="cseg_blur_64x128_r2", kind="blur", H=64, W=128, C=9, offsets=[40, 10],
+                      seed=8000, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
+    specs.append(dict(name="cseg_blur_64x128_r2_s8001", kind="blur", H=64, W=128, C=9, offsets=[40, 10],
+                      seed=8001, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
+    specs.append(dict(name="cseg_checker_96x128_b015", kind="checker", H=96, W=128, C=3,
+                      offsets=[6, 4], seed=4, cell_px=4, opts=(0.0, 1.0, 0.15)))
+    if big:
+        specs.append(dict(name="cseg_blur_256x512_r2", kind="blur", H=256, W=512, C=9,
+                          offsets=[40, 10], seed=8000, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
+        for sd in (6400, 6408):
+            specs.append(dict(name="cseg_crowd48_256x512_s%d" % sd, kind="synth", H=256, W=512, C=9,
+                              offsets=[40, 10], seed=sd, noise=0.15, num_instances=48,
+                              opts=(0.0, 1.0, 0.03)))
     if big:
         specs.append(dict(name="cseg_synth_256x512", kind="synth", H=256, W=512, C=9,
                           offsets=[40, 10], seed=1000, noise=0.15, opts=(0.0, 1.0, 0.03)))

@@ -47,6 +47,13 @@ def load(name):
                            num_instances=spec.get("num_instances"),
                            occlusion=spec.get("occlusion", False))
         cp, sp = s.class_probs, s.sameness_probs
+    elif spec["kind"] == "blur":
+        s = synth.blurred_v1(H, W, C, offs, spec["seed"], radius=spec["radius"], noise=spec["noise"],
+                             num_instances=spec.get("num_instances"))
+        cp, sp = s.class_probs, s.sameness_probs
+    elif spec["kind"] == "checker":
+        s = synth.checkerboard(H, W, C, offs, spec["cell_px"], spec["seed"])
+        cp, sp = s.class_probs, s.sameness_probs
     elif spec["kind"] == "adversarial":
         s = synth.adversarial(H, W, C, offs, spec["seed"])
         cp, sp = s.class_probs, s.sameness_probs

@@ -8,8 +8,9 @@ from mergenet_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-CSEG = gu.names("cseg_")
-TIE_DOMINATED = {"cseg_synth_32x64_n60", "cseg_synth_64x128_n60"}
+ORDER_DEPENDENT = tuple(gu.names("cseg_blur_") + gu.names("cseg_crowd48_") + gu.names("cseg_checker_"))
+CSEG = [n for n in gu.names("cseg_") if n not in ORDER_DEPENDENT]
+TIE_DOMINATED = {"cseg_synth_32x64_n60"}
 PY = gu.names("py_")
 
 
@@ -28,20 +29,70 @@ def _run(g, mode=seg.MN_MODE_AUTO, **kw):
 BIG = [n for n in CSEG if any(t in n for t in ("256x512", "512x1024", "1024x2048", "400x667", "800x1333"))]
 
 
-@pytest.mark.parametrize("name", [n for n in CSEG if n not in BIG])
+@pytest.mark.parametrize("name", [n for n in CSEG if n not in BIG and n not in TIE_DOMINATED])
 def test_golden_csegment(oracle, name):
     """Instance ids equal the REFERENCE's (its compiled segment.cc) up to label permutation."""
     g = gu.load(name)
     noisy = g["spec"]["kind"] == "adversarial" or g["spec"].get("noise", 0.15) > 0.35
     mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT if noisy else seg.MN_MODE_AUTO)
-    if name in TIE_DOMINATED and not oracle.masks_equivalent(mask, classes, g["mask"],
-                                                             g["object_class"]):
-        pytest.xfail("tie-dominated input: ~40 % of the sameness values are clipped to exactly "
-                     "0.99 / 0.01, so thousands of records share one priority and the reference "
-                     "resolves them by heap mechanics (documented difference, DESIGN.md)")
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
     if not noisy and stats["mode_used"] == seg.MN_MODE_ROUNDS:
         assert stats["certified"] == 1
+
+
+@pytest.mark.xfail(strict=True, reason="tie-dominated input: ~40 % of the sameness values are clipped to "
+                   "exactly 0.99 / 0.01, so thousands of records share one priority; the reference resolves "
+                   "them by std::priority_queue heap mechanics and unordered_map iteration order "
+                   "(segment.h:237-242, segment.cc:650-652), EXACT mode by (lowest u, lowest v) "
+                   "(documented difference, DESIGN.md section 5)")
+@pytest.mark.parametrize("name", sorted(TIE_DOMINATED))
+def test_golden_csegment_tie_dominated_exact_mode(oracle, name):
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT)
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
+# ---- order-dependent inputs (round 2): vectors from the reference's own segment.cc ------------------
+# What is PROVEN equal to the reference's sequential order is EXACT mode; the fast modes are
+# approximations of that order on such inputs and say so (certified == 0).  The strict xfails
+# below pin the known gaps: a fix would turn them into failures of the suite and be noticed.
+
+@pytest.mark.parametrize("name", ["cseg_blur_64x128_r2", "cseg_blur_64x128_r2_s8001", "cseg_checker_96x128_b015"])
+def test_order_dependent_goldens_exact_mode_equals_reference(oracle, name):
+    """Maps whose certainty fades at the boundaries (values pass through 0.5) and a bias-dominated
+    checkerboard: the sequential order on the GPU (MN_MODE_EXACT) gives the reference's result."""
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT)
+    assert stats["mode_used"] == seg.MN_MODE_EXACT
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
+@pytest.mark.xfail(strict=True, reason="known gap: on maps that are not sign-separable AUTO falls to the "
+                   "parallel rounds, which reproduce the reference's instance count but assign boundary "
+                   "pixels (0.2-1 % of the image) differently from its sequential order; on the "
+                   "bias-dominated checkerboard the second phase starts from fresh instead of stale "
+                   "priorities (DESIGN.md section 5).  The result carries certified == 0.")
+@pytest.mark.parametrize("name", ["cseg_blur_64x128_r2", "cseg_blur_64x128_r2_s8001", "cseg_blur_256x512_r2",
+                                  "cseg_checker_96x128_b015", "cseg_crowd48_256x512_s6408"])
+def test_order_dependent_goldens_auto_mode_known_gap(oracle, name):
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_AUTO)
+    assert stats["certified"] == 0           # whatever it returns, it must not claim a proof
+    assert stats["proof"] == 0
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
+def test_crowded_48_instance_goldens(oracle):
+    """256x512 images crowded with 48 overlapping instances (slivers of a few pixels): seed 6400 equals
+    the reference in every mode; on seed 6408 the rounds do, components mode does not (strict xfail
+    above) -- neither is proven (certified == 0)."""
+    g = gu.load("cseg_crowd48_256x512_s6400")
+    for mode in (seg.MN_MODE_AUTO, seg.MN_MODE_ROUNDS):
+        mask, classes, part, stats = _run(g, mode)
+        assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), (mode, stats)
+    g = gu.load("cseg_crowd48_256x512_s6408")
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS)
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
 
 
 def test_golden_csegment_256x512_rounds(oracle):
@@ -510,7 +561,7 @@ def test_fuzz_components_mode_on_random_shapes_offsets_and_options(oracle):
     assert used[seg.MN_MODE_COMPONENTS] >= 12, used     # the fast path must be what is mostly tested
 
 
-@pytest.mark.xfail(strict=False, reason="known deviation of the fast modes' second phase: the reference "
+@pytest.mark.xfail(strict=True, reason="known deviation of the fast modes' second phase: the reference "
                    "keeps a record at the priority of its last re-score (taken when the objects were "
                    "smaller), components mode scores the records between components afresh; here one "
                    "record is non-negative afresh but was last scored negative in the reference, so it is "
@@ -558,3 +609,21 @@ def test_compute_logprob_off_skips_certificate_but_not_the_result(oracle):
         mask1, classes1, part1, st1 = _run(g, mode)
         assert np.array_equal(mask, mask1) and classes == classes1
         assert np.isfinite(st1["total_logprob"])
+
+
+def test_require_proof_routes_to_the_sequential_order_or_says_no(oracle):
+    """mn_options.require_proof: a result that is only an approximation of the reference's order is
+    redone in MN_MODE_EXACT when the image is small enough, otherwise the call fails with
+    MN_ERR_UNPROVEN instead of handing back a guess; a certified result passes as it is."""
+    g = gu.load("cseg_blur_64x128_r2")                       # not sign-separable, 80 k records
+    mask, classes, part, st = _run(g, seg.MN_MODE_AUTO, require_proof=1)
+    assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] == seg.MN_PROOF_SEQUENTIAL
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+    g = gu.load("cseg_blur_256x512_r2")                      # 1.25 M records: too many for the sequential mode
+    with pytest.raises(seg.MergeNetError) as e:
+        _run(g, seg.MN_MODE_AUTO, require_proof=1)
+    assert e.value.status == seg.MN_ERR_UNPROVEN
+    g = gu.load("cseg_synth_256x512")                        # separable and certified: nothing to redo
+    mask, classes, part, st = _run(g, seg.MN_MODE_AUTO, require_proof=1)
+    assert st["proof"] == seg.MN_PROOF_CERTIFICATE and st["certified"] == 1
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
