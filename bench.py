@@ -199,7 +199,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    KEYS = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_merge",
+    KEYS = ("ms_class_pass", "ms_edge_pass", "ms_cc_label", "ms_cc_sums", "ms_cc_edges", "ms_cc_cross", "ms_merge",
             "ms_output", "ms_total")
     keys = KEYS
     # initialisation, not a step: one call loads the kernels and sets their attributes, one
@@ -303,9 +303,10 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name)}
 
         if avg["ms_cc_sums"] > 0:      # components mode: labelling, then one sweep per plane kind
-            passes = [price("mn_cc_tiles+mn_cc_borders+mn_cc_hook+mn_cc_flatten", avg["ms_cc_label"], O, "O sameness planes"),
+            passes = [price("mn_cc_sign", avg["ms_cc_edges"], O, "O sameness planes (the only read of them)"),
                       price("mn_cc_class_sums", avg["ms_cc_sums"], C, "C class planes"),
-                      price("mn_cc_edges4", avg["ms_cc_edges"], O, "O sameness planes")]
+                      price("mn_cc_tiles+mn_cc_borders+mn_cc_flatten+mn_cc_hook", avg["ms_cc_label"], 1,
+                            "the 4 B/pixel edge masks (union-find: latency-bound, no roofline claim)")]
         else:
             passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
                       price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]

@@ -109,10 +109,10 @@ typedef struct mn_stats {
   float ms_output;             /* labels, mask, class table, certificate, log-likelihood */
   float ms_total;
   /* components mode only (0 otherwise), HIP events on the launch stream: */
-  float ms_cc_label;           /* mn_cc_tiles + mn_cc_hook + mn_cc_flatten: reads the O sameness planes */
-  float ms_cc_sums;            /* mn_cc_sums: reads the C class planes                                  */
-  float ms_cc_edges;           /* mn_cc_edges: reads the O sameness planes                              */
-  float ms_reserved;
+  float ms_cc_label;           /* mn_cc_tiles + borders + flatten + hook: union-find on the 4 B/pixel masks */
+  float ms_cc_sums;            /* mn_cc_class_sums: reads the C class planes                            */
+  float ms_cc_edges;           /* mn_cc_sign: THE read of the O sameness planes (masks, negative edges)  */
+  float ms_cc_cross;           /* mn_cc_cross: negative-edge list -> records between components         */
   int proof;                   /* why the partition equals the reference's: 0 = not proven (measured
                                   only; an approximation of the sequential order on order-dependent
                                   inputs), 1 = certificate (ANY order of the lazy greedy ends here,

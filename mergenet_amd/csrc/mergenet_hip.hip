@@ -19,8 +19,12 @@
 #include "mn_kernels_prepare.h"
 #include "mn_kernels_cc.h"
 
-// Counters | 8 int scalars | 4 doubles, each part 16-byte aligned
-#define MN_STAT_BYTES ((((sizeof(Counters) + 15) & ~(size_t)15)) + 8 * sizeof(int) + 4 * sizeof(double))
+// Counters | 16 int scalars | 4 doubles, each part 16-byte aligned
+// scalars: [0] edge violations [1] instances [2] objects [3] class violations [4] record violations
+//          [5] RLE change points [6] separability violations [7] table / list overflow
+//          [8] component roots [9] negative edges (unsigned)
+#define MN_NSCALARS 16
+#define MN_STAT_BYTES ((((sizeof(Counters) + 15) & ~(size_t)15)) + MN_NSCALARS * sizeof(int) + 4 * sizeof(double))
 
 #define MN_MAX_SUBROUNDS 64
 
@@ -75,8 +79,12 @@ struct mn_context {
   unsigned char* statblk;
   unsigned char* h_statblk;
   int *cc_tcount, *cc_lcount;   // pixel edges per record: parallel to the components-mode table / list
+  unsigned* cc_bits;            // [N] positive out-edges of every pixel (mn_cc_sign)
+  int* cc_roots;                // [N] component roots (mn_cc_finish)
+  unsigned* cc_negcnt;          // negative edges per block of the sign sweep
+  u64* cc_neglist;              // one region per block of the sign sweep, able to hold every edge of the block
   size_t cc_cap_max;
-  hipEvent_t ev[10];   // 0-4 phases, 6-9 components-mode kernels
+  hipEvent_t ev[12];   // 0-4 phases, 6-11 components-mode kernels
   // mn_segment_launch / mn_segment_finish: what the second half needs of the first
   struct Pending {
     int active;            // 0 none, 1 kernels queued and verdict unread, 2 finished in launch
@@ -179,6 +187,10 @@ static int ctx_alloc(mn_context* c) {
   if (c->cc_cap_max > cap) c->cc_cap_max = cap;
   MN_HIP(dev_alloc(c, &c->cc_tcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->cc_lcount, c->cc_cap_max));
+  MN_HIP(dev_alloc(c, &c->cc_bits, N));
+  MN_HIP(dev_alloc(c, &c->cc_roots, N));
+  MN_HIP(dev_alloc(c, &c->cc_negcnt, N / MN_CC_SIGN_THREADS + 2));
+  MN_HIP(dev_alloc(c, &c->cc_neglist, R + 2 * 1024 * (size_t)c->maxO));
   MN_HIP(dev_alloc(c, &c->T.key, cap));
   MN_HIP(dev_alloc(c, &c->T.S, cap));
   MN_HIP(dev_alloc(c, &c->T.st, cap));
@@ -186,7 +198,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
   MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
   {
-    const size_t o_sc = (sizeof(Counters) + 15) & ~(size_t)15, o_lp = o_sc + 8 * sizeof(int);
+    const size_t o_sc = (sizeof(Counters) + 15) & ~(size_t)15, o_lp = o_sc + MN_NSCALARS * sizeof(int);
     MN_HIP(dev_alloc(c, &c->statblk, MN_STAT_BYTES));
     c->cnt = reinterpret_cast<Counters*>(c->statblk);
     c->scalars = reinterpret_cast<int*>(c->statblk + o_sc);
@@ -200,7 +212,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->theta, 4));
   MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
-  for (int i = 0; i < 10; i++) MN_HIP(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 12; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   return MN_OK;
 }
@@ -237,13 +249,13 @@ extern "C" void mn_destroy(mn_context* c) {
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
-                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->T.key,
+                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->statblk,
                  c->bg_key, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
-  for (int i = 0; i < 10; i++)
+  for (int i = 0; i < 12; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   free(c);
@@ -277,7 +289,12 @@ static void fill_params(ImgParams* P, const float* d_class, const float* d_same,
   P->sdb = o->same_different_bias; P->omf = o->object_merge_factor; P->bias = o->merge_logprob_bias;
   P->variant = o->variant; P->clip = o->clip_inputs ? 1 : 0;
   P->cls = d_class; P->same = d_same;
-  for (int k = 0; k < offset_dim; k++) { P->di[k] = offs[2 * k]; P->dj[k] = offs[2 * k + 1]; }
+  P->djmin = 0; P->djmax = 0;
+  for (int k = 0; k < offset_dim; k++) {
+    P->di[k] = offs[2 * k]; P->dj[k] = offs[2 * k + 1];
+    if (P->dj[k] < P->djmin) P->djmin = P->dj[k];
+    if (P->dj[k] > P->djmax) P->djmax = P->dj[k];
+  }
   // pixel-level upper bound: priority <= (log-odds * omf) / den + bias with den = 2 (csegment) or
   // (log-odds * omf + bias) / 1 (pysegmenter); solve for the sameness value, keep a safety margin
   // a 256-pixel tile row of W = 2048*m pixels puts column band j on XCD j under the identity
@@ -384,8 +401,10 @@ static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool e
   const int N = P.N;
   FillList own;
   if (!fills) fills = &own;
-  fills->add(c->lpvalid, N, 0);
-  fills->add(c->matched, N, 0);
+  if (!components) {                  // (components mode: mn_cc_class_sums writes lpvalid, nothing reads matched)
+    fills->add(c->lpvalid, N, 0);
+    fills->add(c->matched, N, 0);
+  }
   fills->launch(st);
   if (components) {
     MN_HIP(hipEventRecord(c->ev[0], st));
@@ -447,36 +466,63 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
 // sign-separable (object state + list of records between components ready, count in h_cnt), 1
 // when it is not (caller falls back), < 0 on error.  Without: everything is queued, 0 is returned
 // and the verdict is read by the caller at the end.
-static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait) {
+template <int PX>
+static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
+                         u64* neg_list, unsigned sub_cap) {
+  const int N = P.N, ngroups = (N + PX - 1) / PX;
+  if (!hook) {
+    const dim3 g(grid_for(ngroups, MN_CC_SIGN_THREADS)), b(MN_CC_SIGN_THREADS);
+    if (!P.clip && P.sdb == 0.0f)
+      hipLaunchKernelGGL((mn_cc_sign<PX, true>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt,
+                         c->scalars + 6, c->partial);
+    else
+      hipLaunchKernelGGL((mn_cc_sign<PX, false>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt,
+                         c->scalars + 6, c->partial);
+  } else {
+    const dim3 gx(8 * ((grid_for(ngroups, 256) + 7) / 8));
+    hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kmask);
+  }
+}
+
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait, bool with_ball) {
   const int N = P.N;
   ObjState S = obj_state(c);
-  const dim3 b(256), gx(8 * ((grid_for(N, 256) + 7) / 8));
-  // tile stage on the unit offsets (0, +1) and (+-1, 0) if the list has them (generate_offsets
-  // always does); the sweep then takes the shortest offsets first: they connect almost everything
+  const dim3 b(256);
+  const bool four = P.W % 4 == 0;
+  // the unit offsets (0, +1) and (+-1, 0), if the list has them (generate_offsets always does), go
+  // to the tile and border stages; the sweep over the mask takes the rest
   int kh = -1, kv = -1, dv = 0;
   for (int k = 0; k < P.O; k++) {
     if (kh < 0 && P.di[k] == 0 && P.dj[k] == 1) kh = k;
     if (kv < 0 && P.dj[k] == 0 && (P.di[k] == 1 || P.di[k] == -1)) { kv = k; dv = P.di[k]; }
   }
+  // negative-edge list: one region per block of the sign sweep, able to hold every edge of the block
+  u64* neg_list = c->cc_neglist;
+  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);   // per block
   MN_HIP(hipEventRecord(c->ev[6], st));
-  hipLaunchKernelGGL(mn_cc_tiles, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
-                     dim3(1024), 0, st, P, c->parent, kh, kv, dv);
-  int ksplit = P.O < 2 ? P.O : 2;
-  if (kh >= 0 && kv >= 0 && kh < 2 && kv < 2)
-    // the first two offsets are the unit ones: only the tile borders are left of them
-    hipLaunchKernelGGL(mn_cc_borders, dim3((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS),
-                       dim3(128), 0, st, P, c->parent, kh, kv, dv);
-  else
-    hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, 0, ksplit);
-  const bool two = ksplit < P.O;
-  hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
-                     two ? (i64*)nullptr : c->lp_acc);
-  if (two) {
-    hipLaunchKernelGGL(mn_cc_hook, gx, b, 0, st, P, c->parent, ksplit, P.O);
-    hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for(N, 256)), b, 0, st, N, P.C, c->parent, c->osize,
-                       c->lp_acc);
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap);
+  else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
+  MN_HIP(hipEventRecord(c->ev[10], st));
+  const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
+  // class range of the components: `root` and `mapbuf` are free until the output stage
+  int* clsmin = c->root;
+  int* clsmax = c->mapbuf;
+  hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv,
+                     c->osize, c->lp_acc, clsmin, clsmax);
+  unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
+  if (kh >= 0 || kv >= 0) {
+    hipLaunchKernelGGL(mn_cc_borders, tiles, dim3(128), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv);
+    if (kh >= 0) kmask &= ~(1u << kh);
+    if (kv >= 0) kmask &= ~(1u << kv);
   }
-  // the violation counter, the table and the best-record slots were cleared by the caller's fill
+  hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
+  if (kmask) {
+    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap);
+    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap);
+  }
+  // the violation counters, the table and (if asked for) the best-record slots were cleared by the
+  // caller's fill
   HashTab T = c->T;
   T.mask = (unsigned)(c->cc_cap - 1);
   MN_HIP(hipEventRecord(c->ev[7], st));
@@ -489,28 +535,25 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
     }
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
     hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
-                       c->lp_acc);
+                       c->lp_acc, clsmin, clsmax);
   }
   MN_HIP(hipEventRecord(c->ev[8], st));
-  if (P.W % 4 == 0)
-    hipLaunchKernelGGL(mn_cc_edges4, dim3(grid_for((size_t)N / 4, MN_CC_EDGE_THREADS)),
-                       dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
-                       c->scalars + 6, c->cc_tcount, c->partial);
-  else
-    hipLaunchKernelGGL(mn_cc_edges, dim3(8 * ((grid_for(N, MN_CC_EDGE_THREADS) + 7) / 8)),
-                       dim3(MN_CC_EDGE_THREADS), 0, st, P, S, T, (const unsigned char*)c->cls0,
-                       c->scalars + 6);
+  hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
+                     (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
+                     c->scalars + 6, c->cc_tcount);
   MN_HIP(hipEventRecord(c->ev[9], st));
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
   hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc,
-                     c->mate);     // `mate` is free in this mode: it keeps the component sizes
+                     (const int*)clsmin, (const int*)clsmax, c->mate, c->cc_roots, c->scalars + 8,
+                     c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
   hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
-                     T, c->LA, c->ball, c->gmax, c->cnt, (const int*)c->cc_tcount, c->cc_lcount);
+                     T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
+                     (const int*)c->cc_tcount, c->cc_lcount);
   MN_HIP(hipGetLastError());
   if (!wait) return 0;             // speculative: the caller finds out at its final synchronisation
-  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, MN_NSCALARS * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
   if (c->h_scalars[6] != 0 || c->h_scalars[7] != 0) {     // not separable, or the table filled up
@@ -566,9 +609,10 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
     if (mode == MN_MODE_COMPONENTS) {
-      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); stats->ms_cc_label = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[10]); stats->ms_cc_edges = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[10], c->ev[7]); stats->ms_cc_label = ms;
       (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_edges = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_cross = ms;
     }
   }
   g_last_status = rc;
@@ -619,9 +663,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
 
   FillList fills;
   fills.add(c->cnt, sizeof(Counters), 0);
-  fills.add(c->scalars, 8 * sizeof(int), 0);
-  fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);
+  fills.add(c->scalars, MN_NSCALARS * sizeof(int), 0);
   speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
+  if (mode != MN_MODE_COMPONENTS)
+    fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);    // (object -> record) map of mn_finisher
   if (mode == MN_MODE_COMPONENTS) {
     // everything the contraction and the compaction after it expect cleared, in the same launch.
     // Records between components are few: the speculative attempt, which only stands with at
@@ -635,18 +680,20 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     fills.add(c->T.S, cap * sizeof(i64), 0);
     fills.add(c->T.touched, cap, 0);
     fills.add(c->cc_tcount, cap * sizeof(int), 0);
-    fills.add(c->label, (size_t)N * sizeof(int), 0xFF);   // finisher's object -> record map
-    // every best-record slot, not only the components': if more records are left than the
-    // finisher takes, the rounds go on from this list and look at all N slots
-    fills.add(c->ball, (size_t)N * sizeof(u64), 0);
-    fills.add(c->gmax, 64 * sizeof(unsigned), 0);
+    if (!speculate) {
+      // best-record slots: only if more records may be left than the finisher takes, so that the
+      // rounds go on from this list and look at all N slots (the speculative attempt never does:
+      // it is redone on this path instead)
+      fills.add(c->ball, (size_t)N * sizeof(u64), 0);
+      fills.add(c->gmax, 64 * sizeof(unsigned), 0);
+    }
   }
 
   // ---------------- phase A ----------------
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
-    rc = run_components(c, P, st, !speculate);
+    rc = run_components(c, P, st, !speculate, !speculate);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
@@ -731,14 +778,14 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                                    hipFuncAttributeMaxDynamicSharedMemorySize, MN_FIN2_MAXR * 12));
         c->fin_lds_ready = 1;
       }
-      if (mode != MN_MODE_COMPONENTS)   // (cleared by the first fill in components mode)
-        MN_HIP(hipMemsetAsync(c->label, 0xFF, (size_t)N * sizeof(int), st));
       hipLaunchKernelGGL(mn_finisher_lds, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S,
                          cur, R, c->label, c->fin_lists, c->cnt, max_steps,
                          speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr,
                          (const int*)(c->scalars + 6), finish_limit,
                          (mode == MN_MODE_COMPONENTS && rounds == 0) ? c->cc_lcount : (int*)nullptr);
     } else {
+      if (mode == MN_MODE_COMPONENTS)   // (the class range of the contraction lived there)
+        MN_HIP(hipMemsetAsync(c->mapbuf, 0xFF, (size_t)N * sizeof(int), st));
       hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
                          c->touched_list, c->cnt, max_steps);
     }
@@ -768,15 +815,14 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // setting -- the reference's c_run_segmentation returns neither)
   const bool want_cert = opts->compute_logprob != 0;
   if (!want_cert) {
-  } else if (mode == MN_MODE_COMPONENTS && rounds == 0 && P.W % 4 == 0 && R <= MN_FIN2_MAXR) {
+  } else if (mode == MN_MODE_COMPONENTS && rounds == 0 && R <= MN_FIN2_MAXR) {
     // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
     // for the components and the finisher what the merged records moved (mn_cc_certificate)
-    const int nbe = (int)grid_for((size_t)N / 4, MN_CC_EDGE_THREADS), nbc = (int)grid_for(N, MN_CC_CERT_THREADS);
-    double* pcls = c->partial + 2 * (size_t)nbe;
-    hipLaunchKernelGGL(mn_cc_certificate, dim3(nbc), dim3(MN_CC_CERT_THREADS), 0, st, P, S,
-                       (const unsigned char*)c->cls0, (const int*)c->mate, pcls, c->scalars);
-    hipLaunchKernelGGL(mn_cc_cert_reduce, dim3(1), dim3(256), 0, st, nbe, (const double*)c->partial, nbc,
-                       (const double*)pcls, (const Counters*)c->cnt, P.omf, c->lp_out, c->scalars);
+    const int nbe = (int)grid_for((size_t)(P.W % 4 == 0 ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+    hipLaunchKernelGGL(mn_cc_certificate, dim3(1), dim3(MN_CC_CERT_THREADS), 0, st, P, S,
+                       (const unsigned char*)c->cls0, (const int*)c->mate, (const int*)c->cc_roots,
+                       (const int*)(c->scalars + 8), nbe, (const double*)c->partial,
+                       (const Counters*)c->cnt, c->lp_out, c->scalars);
     if (R > 0)
       hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
                          c->scalars, speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr);

@@ -22,6 +22,7 @@ struct ImgParams {
   float sdb, omf, bias;
   int variant, clip;
   int banded;          // 1: XCD-banded tile order in the neighbour-reading kernels (mn_xcd_tile)
+  int djmin, djmax;    // smallest / largest column offset of the list
   float vmin_first;    // pixel-level edges with a raw sameness value below this cannot reach priority >= 0
   float sep_hi, sep_lo; // components mode: an edge inside a component needs a sameness value >= sep_hi,
                         // one between components <= sep_lo (0.5 widened by the float32 rounding margin)

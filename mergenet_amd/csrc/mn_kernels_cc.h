@@ -13,16 +13,23 @@
 // popped while any intra record is alive: the reference first merges every component completely
 // -- in whatever order -- and only then turns to the records between components.  The state at
 // that moment (objects = components, one fully summed record per adjacent pair) is what this
-// file builds directly:
-//   mn_cc_tiles    16 x 64-pixel tiles labelled in LDS over the two unit offsets;
-//   mn_cc_hook     lock-free union-find over the implicit pixel graph (positive edges), root =
-//                  lowest pixel id of the component; unit offsets first, then the rest;
-//   mn_cc_flatten  parent[p] = root (and the roots' accumulators cleared);
-//   mn_cc_class_sums  the class pass: arg-max class of every pixel, component sizes and class
-//                  log-prob sums (block table in LDS, 64-bit fixed-point atomics);
-//   mn_cc_edges    conditions (a), (b), (c); records between components summed into
-//                  the hash table (per lane while the key repeats, then per block in LDS);
-//   mn_cc_finish   fixed-point sums -> float object state.
+// file builds directly.  The O sameness planes are read from HBM exactly ONCE:
+//   mn_cc_sign     THE sweep over the sameness planes (4 B per value, the roofline-judged pass of
+//                  this mode): per pixel a bit mask of its positive out-edges (4 B/pixel), the
+//                  margin test of (a)/(b), the log sums of the certificate, and a compact list of
+//                  the negative edges (edge id, log-odds) -- the only edges whose value is needed
+//                  again; everything after this kernel works on the 4 B/pixel mask;
+//   mn_cc_tiles    16 x 64-pixel tiles labelled in LDS over the two unit offsets (mask bits); flat
+//                  within the tile; accumulators of the tile roots cleared;
+//   mn_cc_borders  unit-offset edges across tile borders; mn_cc_flatten  parent[p] = root, once;
+//   mn_cc_hook     lock-free union-find over the other offsets (mask bits), root = lowest pixel id
+//                  of the component;
+//   mn_cc_class_sums  the class pass: arg-max class of every pixel, component sizes, class
+//                  log-prob sums and class range (block table in LDS, 64-bit fixed-point atomics);
+//                  also leaves parent[] flat;
+//   mn_cc_cross    the negative-edge list -> records between components (block table in LDS,
+//                  then the global table); a negative edge inside a component fails (a);
+//   mn_cc_finish   fixed-point sums -> float object state, condition (c), list of component roots.
 // The second phase (records between components, where the bias lets a 1.6 M-pixel background
 // swallow small instances) is then run by the sequential finisher in the reference's order,
 // starting from freshly scored records.  If (a)-(c) fail the caller falls back to the general
@@ -46,58 +53,255 @@ __device__ __forceinline__ int mn_cc_find(int* __restrict__ parent, int x) {
   return x;
 }
 
+struct __attribute__((packed, aligned(4))) mn_int4u { int x, y, z, w; };
+__device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) {
+  const mn_int4u t = *reinterpret_cast<const mn_int4u*>(p);
+  return make_int4(t.x, t.y, t.z, t.w);
+}
+
+// ---- the sweep over the sameness planes ---------------------------------------------------------
+// One lane takes PX consecutive pixels of one row (PX = 4 with 16-byte loads when W % 4 == 0, else
+// 1).  For every in-bounds (pixel, offset) pair the value decides: >= sep_hi the edge is positive
+// (bit k of the pixel's mask), <= sep_lo it is negative (the edge goes to the compact list), in
+// between the map is not separable (margins: fill_params).  The negative edges -- a few per cent,
+// along the instance boundaries -- are the only ones whose value is needed again (log-odds of the
+// records between components), so they leave as 8-byte entries  (offset << 26 | pixel) << 32 |
+// float bits of the log-odds  and nothing downstream reads the planes again.
+// Algorithmic HBM bytes: 4 * O per pixel read (83.9 MB at 1024x2048, O = 10).
+//
+// The pass is VALU-bound as soon as a value costs more than ~15 instructions (a wave64
+// instruction takes 4 cycles; PMC: the first version ran 54 per value, 70 % VALU-busy), so:
+//  * a wave whose pixels have every offset's column inside the image (all but the first and last
+//    waves of a row) skips the per-value bounds tests: a row outside the image just loads 1.0;
+//  * the certificate only needs  sum log v (inside) + sum log(1-v) (between) = sum log max(v, 1-v)
+//    on a separable map, taken as the log of a PRODUCT per lane (factors in [0.5, 1], folded
+//    every 80 factors): one max and one multiply per value instead of a log;
+//  * negative edges are counted by popcount, queued in LDS as 2-byte items (pixel in block,
+//    offset) and then worked off by ALL lanes of the block, one item each (load the value again --
+//    an L2 / Infinity Cache hit --, logf, log(1-v), write): dense work and coalesced writes
+//    instead of 40 divergent iterations in the few lanes that sit on a boundary.
+// Every block owns a fixed region of the list, large enough for all its edges (256 * PX * O
+// entries; 288 GB of HBM make that affordable: 168 MB at 1024x2048), and leaves its count in
+// neg_count[block]: no atomic, no reservation to wait for.  PLAIN: no clip and no
+// same_different_bias (the production setting), decided at compile time.
+#define MN_CC_SIGN_THREADS 256
+#define MN_CC_SIGN_G 5           /* offsets whose loads are in flight together */
+#define MN_CC_EDGE_PIXBITS 26    /* components mode serves N <= 2^26 */
+
+template <bool PLAIN>
+__device__ __forceinline__ float mn_cc_value(const ImgParams& P, float v) {
+  return PLAIN ? v : mn_same_value(P, v);
+}
+
+template <int PX, bool PLAIN>
+__global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
+    ImgParams P, unsigned* __restrict__ bits, u64* __restrict__ neg_list, unsigned sub_cap,
+    unsigned* __restrict__ neg_count, int* __restrict__ violations, double* __restrict__ partial) {
+  __shared__ double s_part[MN_CC_SIGN_THREADS / 64];
+  __shared__ int s_w[MN_CC_SIGN_THREADS / 64];
+  __shared__ unsigned short s_item[MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS > 10240
+                                       ? 10240 : MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS];
+  constexpr int QCAP = MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS > 10240 ? 10240 : MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ngroups = (P.N + PX - 1) / PX;
+  const int i = blockIdx.x * MN_CC_SIGN_THREADS + threadIdx.x;
+  const bool live = i < ngroups;
+  const int p0 = live ? PX * i : 0;
+  const int r = p0 / P.W, c0 = p0 - r * P.W;
+  float f = 1.0f;
+  double t_sum = 0.0;
+  unsigned m[PX], ng[PX];                                // positive / negative out-edges per pixel
+#pragma unroll
+  for (int j = 0; j < PX; j++) { m[j] = 0u; ng[j] = 0u; }
+  unsigned inmask[PX];                                   // in-bounds out-edges per pixel
+#pragma unroll
+  for (int j = 0; j < PX; j++) inmask[j] = 0u;
+  constexpr int G = MN_CC_SIGN_G;
+  // every pixel of every lane of this wave has all offsets' columns inside the image?
+  const bool colsafe = live && c0 + P.djmin >= 0 && c0 + PX - 1 + P.djmax < P.W;
+  const bool fast = __all(colsafe);
+  unsigned rowmask = 0u;                                 // offsets whose row is inside the image
+  for (int k0 = 0; k0 < P.O; k0 += G) {
+    float v[G][PX];
+    int first[G];                                       // column of the first neighbour, or INT_MIN
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int k = k0 + g;
+      first[g] = INT_MIN;
+#pragma unroll
+      for (int j = 0; j < PX; j++) v[g][j] = 1.0f;      // neutral: factor 1, its bits are masked off
+      if (live && k < P.O) {
+        const int rr = r + P.di[k];
+        if (rr >= 0 && rr < P.H) {
+          first[g] = c0 + P.dj[k];
+          rowmask |= 1u << k;
+          if (PX == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
+            v[g][0] = t.x; v[g][1 % PX] = t.y; v[g][2 % PX] = t.z; v[g][3 % PX] = t.w;
+          } else {
+            v[g][0] = P.same[(size_t)k * P.N + p0];
+          }
+        }
+      }
+    }
+    if (fast) {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const unsigned bit = 1u << ((k0 + g) & 31);
+#pragma unroll
+        for (int j = 0; j < PX; j++) {
+          const float x = (PLAIN || first[g] != INT_MIN) ? mn_cc_value<PLAIN>(P, v[g][j]) : 1.0f;
+          m[j] |= (x >= P.sep_hi) ? bit : 0u;
+          ng[j] |= (x <= P.sep_lo) ? bit : 0u;
+          f *= fmaxf(x, 1.0f - x);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const unsigned bit = 1u << ((k0 + g) & 31);
+#pragma unroll
+        for (int j = 0; j < PX; j++) {
+          // first[g] == INT_MIN (row outside / no such offset) fails the column test
+          const bool inb = (unsigned)(first[g] + j) < (unsigned)P.W;
+          const float x = inb ? mn_cc_value<PLAIN>(P, v[g][j]) : 1.0f;
+          inmask[j] |= inb ? bit : 0u;
+          m[j] |= (x >= P.sep_hi) ? bit : 0u;
+          ng[j] |= (x <= P.sep_lo) ? bit : 0u;
+          f *= fmaxf(x, 1.0f - x);
+        }
+      }
+    }
+    if (((k0 / G) & 3) == 3 || k0 + G >= P.O) {         // at most 4 * G * PX = 80 factors per product
+      t_sum += (double)logf(f);
+      f = 1.0f;
+    }
+  }
+  int bad = 0, nneg = 0;
+#pragma unroll
+  for (int j = 0; j < PX; j++) {
+    const unsigned in = fast ? rowmask : inmask[j];
+    m[j] &= in;
+    ng[j] &= in;
+    nneg += __popc(ng[j]);
+    bad += __popc(in & ~(m[j] | ng[j]));                // inside the rounding margin of 0.5
+  }
+  if (live) {
+    if (PX == 4) *reinterpret_cast<uint4*>(bits + p0) = make_uint4(m[0], m[1 % PX], m[2 % PX], m[3 % PX]);
+    else bits[p0] = m[0];
+  }
+  // block scan of the lanes' negative-edge counts
+  int incl = nneg;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  for (int off = 32; off > 0; off >>= 1) {
+    bad += __shfl_xor(bad, off);
+    t_sum += __shfl_xor(t_sum, off);
+  }
+  if (lane == 0) {
+    if (bad) atomicAdd(violations, bad);
+    s_part[wave] = t_sum;
+  }
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < MN_CC_SIGN_THREADS / 64; w++) { if (w < wave) woff += s_w[w]; total += s_w[w]; }
+  if (threadIdx.x == 0) {
+    neg_count[blockIdx.x] = (unsigned)total;
+    double t = 0.0;                                     // block order: the sum is reproducible
+    for (int w = 0; w < MN_CC_SIGN_THREADS / 64; w++) t += s_part[w];
+    partial[(size_t)blockIdx.x * 2] = t;                // (inside + between; the split is not needed)
+    partial[(size_t)blockIdx.x * 2 + 1] = 0.0;
+  }
+  if (total == 0) return;                               // uniform
+  u64* __restrict__ mylist = neg_list + (size_t)blockIdx.x * sub_cap;
+  // queue: item = (pixel within the block << 5) | offset, at the position the scan gives
+  for (int q0 = 0; q0 < total; q0 += QCAP) {            // (one pass unless O * PX * 256 > QCAP)
+    int pos = woff + incl - nneg - q0;
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      unsigned bitsleft = ng[j];
+      while (bitsleft) {
+        const int k = __ffs((int)bitsleft) - 1;
+        bitsleft &= bitsleft - 1u;
+        if (pos >= 0 && pos < QCAP) s_item[pos] = (unsigned short)(((threadIdx.x * PX + j) << 5) | k);
+        pos++;
+      }
+    }
+    __syncthreads();
+    const int nq = min(QCAP, total - q0);
+    for (int t = threadIdx.x; t < nq; t += MN_CC_SIGN_THREADS) {
+      const unsigned it = s_item[t];
+      const int k = (int)(it & 31u);
+      const int p = blockIdx.x * (MN_CC_SIGN_THREADS * PX) + (int)(it >> 5);
+      const float x = mn_cc_value<PLAIN>(P, P.same[(size_t)k * P.N + p]);
+      const float oml = logf(x) - mn_log1m(x);
+      if ((unsigned)(q0 + t) < sub_cap)
+        mylist[q0 + t] = ((u64)(((unsigned)k << MN_CC_EDGE_PIXBITS) | (unsigned)p) << 32) |
+                         (u64)__float_as_uint(oml);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- labelling on the 4 B/pixel masks -----------------------------------------------------------
 // Tile stage: a block owns a tile of 16 rows x 64 columns and labels it in LDS.
 //  1. rows, no atomics: a wave covers the 64 pixels of one tile row; lanes joined by positive edges
-//     of the horizontal unit offset (index kh, direction +1 column) form runs, and every pixel
+//     of the horizontal unit offset (bit kh, direction +1 column) form runs, and every pixel
 //     points at the first pixel of its run (one ballot and bit arithmetic);
-//  2. columns: positive edges of the vertical unit offset (index kv, direction dv = +-1 row) that
+//  2. columns: positive edges of the vertical unit offset (bit kv, direction dv = +-1 row) that
 //     stay inside the tile are united by a union-find on the LDS labels (one lane per distinct
 //     pair of roots in a wave);
 //  3. the flattened labels go to `parent` as pixel ids.  Local order (row, column) is the global
 //     pixel order, so "larger root under smaller" keeps holding across stages.
-// The global sweep that follows then only does real work on tile borders: 1/16 of the vertical and
-// 1/64 of the horizontal unit edges, against trees that are already flat.
 #define MN_CC_TILE_ROWS 16
-__global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, int* __restrict__ parent, int kh,
-                                                    int kv, int dv) {
+//  4. every pixel's component size starts at 0 and the accumulators of the TILE roots are cleared
+//     (class sums -- only the roots' slots of the C planes are ever used -- and class range): the
+//     stages that follow only remove roots, so the final roots are among them.
+__global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, const unsigned* __restrict__ bits,
+                                                    int* __restrict__ parent, int kh, int kv, int dv,
+                                                    int* __restrict__ osize, i64* __restrict__ lp_acc,
+                                                    int* __restrict__ clsmin, int* __restrict__ clsmax) {
   __shared__ int lab[MN_CC_TILE_ROWS * 64];
   const int t = threadIdx.x, lane = t & 63, i = t >> 6;
   const int r = (int)blockIdx.y * MN_CC_TILE_ROWS + i, c = (int)blockIdx.x * 64 + lane;
   const bool in = r < P.H && c < P.W;
   const int p = in ? r * P.W + c : 0;
-  bool link = false;                         // positive edge between this pixel and the next one
-  if (in && kh >= 0 && c + 1 < P.W) link = mn_same_value(P, P.same[(size_t)kh * P.N + p]) > 0.5f;
-  bool vlink = false;
+  const unsigned b = in ? bits[p] : 0u;                // a set bit implies an in-bounds neighbour
+  const bool link = kh >= 0 && ((b >> kh) & 1u) && lane < 63;   // next pixel in the same tile row
   const int ni = i + dv;
-  if (in && kv >= 0 && ni >= 0 && ni < MN_CC_TILE_ROWS && r + dv >= 0 && r + dv < P.H)
-    vlink = mn_same_value(P, P.same[(size_t)kv * P.N + p]) > 0.5f;
+  const bool vlink = kv >= 0 && ((b >> kv) & 1u) && ni >= 0 && ni < MN_CC_TILE_ROWS;
   const u64 m = __ballot(link);
   // run start = one past the highest lane below `lane` that has NO link to its successor
   const u64 below = lane ? (~m & ((1ull << lane) - 1ull)) : 0ull;
   const int start = below ? (64 - __clzll((long long)below)) : 0;
   lab[t] = i * 64 + start;
   __syncthreads();
-  int a = 0, b = 0;
+  int a = 0, bb = 0;
   bool want = false;
   if (vlink) {
     a = mn_cc_find(lab, t);
-    b = mn_cc_find(lab, ni * 64 + lane);
-    want = a != b;
+    bb = mn_cc_find(lab, ni * 64 + lane);
+    want = a != bb;
   }
   u64 todo = __ballot(want);
-  const u64 key = mn_key(a, b);
+  const u64 key = mn_key(a, bb);
   while (todo) {
     const int first = __ffsll((long long)todo) - 1;
     const u64 k0v = ((u64)(unsigned)__shfl((int)(key >> 32), first) << 32) |
                     (u64)(unsigned)__shfl((int)(key & 0xFFFFFFFFull), first);
     const bool mine = want && key == k0v;
     if (lane == first) {
-      while (a != b) {                                  // hook the larger root under the smaller
-        if (a < b) { const int x = a; a = b; b = x; }
-        const int old = atomicMin(&lab[a], b);
+      while (a != bb) {                                 // hook the larger root under the smaller
+        if (a < bb) { const int x = a; a = bb; bb = x; }
+        const int old = atomicMin(&lab[a], bb);
         if (old == a) break;
         a = mn_cc_find(lab, old);
-        b = mn_cc_find(lab, b);
+        bb = mn_cc_find(lab, bb);
       }
     }
     todo &= ~__ballot(mine);
@@ -107,38 +311,18 @@ __global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, int* __restrict
   int x = t;
   while (lab[x] != x) x = lab[x];
   parent[p] = ((int)blockIdx.y * MN_CC_TILE_ROWS + (x >> 6)) * P.W + (int)blockIdx.x * 64 + (x & 63);
+  osize[p] = 0;
+  if (x == t) {
+    for (int c = 0; c < P.C; c++) lp_acc[(size_t)c * P.N + p] = 0;
+    clsmin[p] = 255;
+    clsmax[p] = 0;
+  }
 }
 
-// Border stage: after mn_cc_tiles the only unit-offset edges still open are those that cross a
-// tile border, and the 16 (or 64) edges of one border segment almost always ask for the same
-// union.  One block per tile: wave 0 takes the 16 edges across the tile's right border, wave 1 the
-// 64 edges across its lower (dv = +1) or upper (dv = -1) border; one lane per distinct pair of
-// roots does the union.  ~4 K unions for a 1024x2048 image instead of a sweep over every pixel.
-__global__ __launch_bounds__(128) void mn_cc_borders(ImgParams P, int* __restrict__ parent, int kh,
-                                                     int kv, int dv) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r0 = (int)blockIdx.y * MN_CC_TILE_ROWS, c0 = (int)blockIdx.x * 64;
-  int p = -1, q = -1;
-  if (wave == 0) {                                   // right border: (r0 + lane, c0 + 63) -> next column
-    const int r = r0 + lane, c = c0 + 63;
-    if (lane < MN_CC_TILE_ROWS && r < P.H && c + 1 < P.W) {
-      p = r * P.W + c;
-      if (mn_same_value(P, P.same[(size_t)kh * P.N + p]) > 0.5f) q = p + 1;
-    }
-  } else {                                           // the border the vertical offset crosses
-    const int r = dv > 0 ? r0 + MN_CC_TILE_ROWS - 1 : r0, c = c0 + lane;
-    if (r < P.H && r + dv >= 0 && r + dv < P.H && c < P.W) {
-      p = r * P.W + c;
-      if (mn_same_value(P, P.same[(size_t)kv * P.N + p]) > 0.5f) q = p + dv * P.W;
-    }
-  }
-  int a = 0, b = 0;
-  bool want = false;
-  if (q >= 0) {
-    a = mn_cc_find(parent, p);
-    b = mn_cc_find(parent, q);
-    want = a != b;
-  }
+// one lane per distinct pair of roots of a wave does the union (the 64 pixels of a wave mostly ask
+// for the same few unions: runs of a row against the runs of another row)
+__device__ __forceinline__ void mn_cc_wave_union(int* __restrict__ parent, bool want, int a, int b) {
+  const int lane = threadIdx.x & 63;
   u64 todo = __ballot(want);
   const u64 key = mn_key(a, b);
   while (todo) {
@@ -148,7 +332,7 @@ __global__ __launch_bounds__(128) void mn_cc_borders(ImgParams P, int* __restric
     const bool mine = want && key == k0v;
     if (lane == first) {
       while (a != b) {                                  // hook the larger root under the smaller
-        if (a < b) { const int x = a; a = b; b = x; }
+        if (a < b) { const int t = a; a = b; b = t; }
         const int old = atomicMin(&parent[a], b);
         if (old == a) break;
         a = mn_cc_find(parent, old);
@@ -159,95 +343,139 @@ __global__ __launch_bounds__(128) void mn_cc_borders(ImgParams P, int* __restric
   }
 }
 
-// Offsets [k0, k1) only: the sweep runs first over the two unit offsets, which already connect
-// almost every component, is flattened, and then runs over the rest, whose edges then find equal
-// roots at once (no atomic).
-__global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, int* __restrict__ parent, int k0,
-                                                  int k1) {
-  const int tile = mn_xcd_tile((P.N + 255) >> 8, P.banded);
-  if (tile < 0) return;
-  const int p = tile * 256 + threadIdx.x;
-  const bool live = p < P.N;
-  const int lane = threadIdx.x & 63;
-  const int r = live ? p / P.W : 0, c = live ? p - r * P.W : 0;
-  constexpr int G = 4;                        // offsets whose loads are in flight together
-  for (int kb = k0; kb < k1; kb += G) {
-    float vv[G];
-    int pq[G], qq[G];
-    const int pp = live ? parent[p] : 0;
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      const int k = kb + j;
-      vv[j] = 0.0f;
-      pq[j] = pp;
-      qq[j] = -1;
-      if (live && k < k1) {
-        const int rr = r + P.di[k], cc = c + P.dj[k];
-        if (rr >= 0 && rr < P.H && cc >= 0 && cc < P.W) {
-          qq[j] = rr * P.W + cc;
-          vv[j] = P.same[(size_t)k * P.N + p];
-          pq[j] = parent[qq[j]];
-        }
-      }
+// Border stage: after mn_cc_tiles the only unit-offset edges still open are those that cross a
+// tile border, and the 16 (or 64) edges of one border segment almost always ask for the same
+// union.  One block per tile: wave 0 takes the 16 edges across the tile's right border, wave 1 the
+// 64 edges across its lower (dv = +1) or upper (dv = -1) border.
+__global__ __launch_bounds__(128) void mn_cc_borders(ImgParams P, const unsigned* __restrict__ bits,
+                                                     int* __restrict__ parent, int kh, int kv, int dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (int)blockIdx.y * MN_CC_TILE_ROWS, c0 = (int)blockIdx.x * 64;
+  int p = -1, q = -1;
+  if (wave == 0) {                                   // right border: (r0 + lane, c0 + 63) -> next column
+    const int r = r0 + lane, c = c0 + 63;
+    if (kh >= 0 && lane < MN_CC_TILE_ROWS && r < P.H && c + 1 < P.W) {
+      p = r * P.W + c;
+      if ((bits[p] >> kh) & 1u) q = p + 1;
     }
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-    if (kb + j >= k1) break;                  // uniform
-    bool want = false;
-    int a = 0, b = 0;
-    if (qq[j] >= 0 && pq[j] != pp) {          // equal parents: already one set, nothing to do
-      const float v = mn_same_value(P, vv[j]);
-      if (v > 0.5f) {                         // log-odds > 0 (see mn_cc_edges)
-        a = mn_cc_find(parent, p);
-        b = mn_cc_find(parent, qq[j]);
-        want = a != b;
-      }
+  } else {                                           // the border the vertical offset crosses
+    const int r = dv > 0 ? r0 + MN_CC_TILE_ROWS - 1 : r0, c = c0 + lane;
+    if (kv >= 0 && r < P.H && r + dv >= 0 && r + dv < P.H && c < P.W) {
+      p = r * P.W + c;
+      if ((bits[p] >> kv) & 1u) q = p + dv * P.W;
     }
-    // the 64 pixels of a wave mostly ask for the same few unions (runs of a row against the runs
-    // of another row): one lane per distinct (root, root) pair does it
-    u64 todo = __ballot(want);
-    const u64 key = mn_key(a, b);
-    while (todo) {
-      const int first = __ffsll((long long)todo) - 1;
-      const u64 k0v = ((u64)(unsigned)__shfl((int)(key >> 32), first) << 32) |
-                      (u64)(unsigned)__shfl((int)(key & 0xFFFFFFFFull), first);
-      const bool mine = want && key == k0v;
-      if (lane == first) {
-        while (a != b) {                                // hook the larger root under the smaller
-          if (a < b) { const int t = a; a = b; b = t; }
-          const int old = atomicMin(&parent[a], b);
-          if (old == a) break;
-          a = mn_cc_find(parent, old);
-          b = mn_cc_find(parent, b);
-        }
-      }
-      todo &= ~__ballot(mine);
-    }
-    }
+  }
+  int a = 0, b = 0;
+  bool want = false;
+  if (q >= 0) {
+    a = mn_cc_find(parent, p);
+    b = mn_cc_find(parent, q);
+    want = a != b;
+  }
+  mn_cc_wave_union(parent, want, a, b);
+}
+
+// parent[p] = root, once, between the border stage and the sweep over the other offsets (4 pixels
+// per lane; every pixel already points at its tile root, so the chase is one or two steps)
+__global__ __launch_bounds__(256) void mn_cc_flatten(int N, int* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i < n4) {
+    int4 r = *reinterpret_cast<const int4*>(parent + 4 * (size_t)i);
+    int4 o = r;
+    int x = r.x; while (parent[x] != x) x = parent[x]; o.x = x;
+    if (r.y == r.x) o.y = o.x; else { x = r.y; while (parent[x] != x) x = parent[x]; o.y = x; }
+    if (r.z == r.x) o.z = o.x; else { x = r.z; while (parent[x] != x) x = parent[x]; o.z = x; }
+    if (r.w == r.x) o.w = o.x; else { x = r.w; while (parent[x] != x) x = parent[x]; o.w = x; }
+    if (o.x != r.x || o.y != r.y || o.z != r.z || o.w != r.w)
+      *reinterpret_cast<int4*>(parent + 4 * (size_t)i) = o;
+  }
+  if (i < N - (n4 << 2)) {
+    const int p = (n4 << 2) + i;
+    int x = p; while (parent[x] != x) x = parent[x];
+    parent[p] = x;
   }
 }
 
-// `lp_acc` set (last flatten): component sizes and the class sums of the roots start from zero --
-// only the roots' slots of the C planes are ever used, so they are cleared here instead of by a
-// memset of all C * N words.
-__global__ __launch_bounds__(256) void mn_cc_flatten(int N, int C, int* __restrict__ parent,
-                                                     int* __restrict__ osize,
-                                                     i64* __restrict__ lp_acc) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N) return;
-  int x = p;
-  while (parent[x] != x) x = parent[x];
-  parent[p] = x;
-  if (lp_acc) {
-    osize[p] = 0;
-    if (x == p)
-      for (int c = 0; c < C; c++) lp_acc[(size_t)c * N + p] = 0;
+// The offsets of `kmask` (all but the unit offsets the tile and border stages took): after the
+// flatten nearly every positive edge finds equal parents at both ends and costs two L2 reads.
+template <int PX>
+__global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* __restrict__ bits,
+                                                  int* __restrict__ parent, unsigned kmask) {
+  const int ngroups = (P.N + PX - 1) / PX;
+  const int tile = mn_xcd_tile((ngroups + 255) >> 8, P.banded);
+  const int i = tile < 0 ? ngroups : tile * 256 + threadIdx.x;
+  const bool live = i < ngroups;
+  const int p0 = live ? PX * i : 0;
+  const int r = p0 / P.W, c0 = p0 - r * P.W;
+  unsigned b[PX];
+  int own[PX];
+#pragma unroll
+  for (int j = 0; j < PX; j++) { b[j] = 0u; own[j] = 0; }
+  if (live) {
+    if (PX == 4) {
+      const uint4 t = *reinterpret_cast<const uint4*>(bits + p0);
+      b[0] = t.x; b[1 % PX] = t.y; b[2 % PX] = t.z; b[3 % PX] = t.w;
+      const int4 o = *reinterpret_cast<const int4*>(parent + p0);
+      own[0] = o.x; own[1 % PX] = o.y; own[2 % PX] = o.z; own[3 % PX] = o.w;
+    } else {
+      b[0] = bits[p0];
+      own[0] = parent[p0];
+    }
+  }
+  unsigned any = 0u;
+#pragma unroll
+  for (int j = 0; j < PX; j++) any |= b[j];
+  any &= kmask;
+  constexpr int G = 4;                        // offsets whose loads are in flight together
+  for (int k0 = 0; k0 < P.O; k0 += G) {
+    if (__ballot((any >> k0) & ((1u << G) - 1u)) == 0) continue;          // uniform
+    int rq[G][PX];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int k = k0 + g;
+#pragma unroll
+      for (int j = 0; j < PX; j++) rq[g][j] = own[j];
+      if (k < P.O && ((any >> k) & 1u)) {
+        const long long q0 = (long long)(r + P.di[k]) * P.W + c0 + P.dj[k];
+        if (PX == 4 && q0 >= 0 && q0 + 3 < P.N) {
+          const int4 t = mn_ld_int4_unaligned(parent + q0);
+          rq[g][0] = t.x; rq[g][1 % PX] = t.y; rq[g][2 % PX] = t.z; rq[g][3 % PX] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < PX; j++)
+            if (((b[j] >> k) & 1u) && q0 + j >= 0 && q0 + j < P.N) rq[g][j] = parent[q0 + j];
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int k = k0 + g;
+      if (k >= P.O) break;                    // uniform
+      if (__ballot((any >> k) & 1u) == 0) continue;
+#pragma unroll
+      for (int j = 0; j < PX; j++) {
+        bool want = false;
+        int a = 0, bb = 0;
+        if (((b[j] & kmask) >> k) & 1u) {     // a set bit implies an in-bounds neighbour
+          if (rq[g][j] != own[j]) {           // equal parents: already one set, nothing to do
+            const int q = p0 + j + P.di[k] * P.W + P.dj[k];
+            a = mn_cc_find(parent, p0 + j);
+            bb = mn_cc_find(parent, q);
+            want = a != bb;
+          }
+        }
+        mn_cc_wave_union(parent, want, a, bb);
+      }
+    }
   }
 }
 
 // Class pass of components mode: one sweep over the C class planes gives every pixel its arg-max
 // class (same rule as mn_class_pass: first maximum of logf) AND adds its class log-probs and its
-// count to the sums of its component.  4 consecutive pixels per lane (16-byte loads); a lane whose
+// count to the sums of its component, and the component's class range (condition (c): one class
+// per component <=> min == max).  The sweep also leaves parent[] flat (every pixel -> its root:
+// no union happens after the hook stage) and clears lpvalid.  4 consecutive pixels per lane (16-byte loads); a lane whose
 // four pixels share a root -- nearly all do -- issues one LDS atomic per class into the block's
 // table (root -> C+1 fixed-point sums); the block then issues ONE global atomic per root and class:
 // a 1.6 M-pixel background is a hot word for every wave of the image, and one word takes only ~88
@@ -267,6 +495,12 @@ __device__ __forceinline__ int mn_lds_root_slot(int* s_root, int root) {
   return -1;
 }
 
+__device__ __forceinline__ int mn_cc_root_ro(const int* __restrict__ parent, int x) {
+  int p = parent[x];
+  while (p != x) { x = p; p = parent[x]; }
+  return x;
+}
+
 __device__ __forceinline__ void mn_cc_add(const ImgParams& P, const ObjState& S, int* s_root,
                                           u64* s_val, i64* __restrict__ lp_acc, int root, int c,
                                           int slot, i64 x) {
@@ -275,19 +509,40 @@ __device__ __forceinline__ void mn_cc_add(const ImgParams& P, const ObjState& S,
   else atomicAdd(reinterpret_cast<u64*>(&lp_acc[(size_t)c * P.N + root]), (u64)x);
 }
 
+__device__ __forceinline__ void mn_cc_cls(int* s_min, int* s_max, int* __restrict__ clsmin,
+                                          int* __restrict__ clsmax, int root, int slot, int lo, int hi) {
+  if (slot >= 0) {
+    if (lo < s_min[slot]) atomicMin(&s_min[slot], lo);
+    if (hi > s_max[slot]) atomicMax(&s_max[slot], hi);
+  } else {
+    atomicMin(&clsmin[root], lo);
+    atomicMax(&clsmax[root], hi);
+  }
+}
+
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
-    ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc) {
+    ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc,
+    int* __restrict__ clsmin, int* __restrict__ clsmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
   __shared__ int s_root[MN_CC_SUM_SLOTS];
+  __shared__ int s_min[MN_CC_SUM_SLOTS];
+  __shared__ int s_max[MN_CC_SUM_SLOTS];
   const int nval = MN_CC_SUM_SLOTS * (P.C + 1);
   for (int i = threadIdx.x; i < nval; i += MN_CC_SUM_THREADS) s_val[i] = 0;
-  if (threadIdx.x < MN_CC_SUM_SLOTS) s_root[threadIdx.x] = -1;
+  if (threadIdx.x < MN_CC_SUM_SLOTS) { s_root[threadIdx.x] = -1; s_min[threadIdx.x] = 255; s_max[threadIdx.x] = 0; }
   __syncthreads();
   const int n4 = P.N >> 2;
   const int i = blockIdx.x * MN_CC_SUM_THREADS + threadIdx.x;
   if (i < n4) {
-    const int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
+    int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
+    // after the hook stage a parent may still be one or two steps from its root
+    r.x = mn_cc_root_ro(S.parent, r.x);
+    r.y = r.y == r.x ? r.x : mn_cc_root_ro(S.parent, r.y);
+    r.z = r.z == r.x ? r.x : mn_cc_root_ro(S.parent, r.z);
+    r.w = r.w == r.x ? r.x : mn_cc_root_ro(S.parent, r.w);
+    *reinterpret_cast<int4*>(S.parent + 4 * (size_t)i) = r;
+    *reinterpret_cast<uchar4*>(S.lpvalid + 4 * (size_t)i) = make_uchar4(0, 0, 0, 0);
     const bool same = r.x == r.y && r.x == r.z && r.x == r.w;
     const int s0 = mn_lds_root_slot(s_root, r.x);
     const int s1 = same ? s0 : mn_lds_root_slot(s_root, r.y);
@@ -340,12 +595,22 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     o.x = (unsigned char)b0; o.y = (unsigned char)b1; o.z = (unsigned char)b2; o.w = (unsigned char)b3;
     *reinterpret_cast<uchar4*>(S.ocls + 4 * (size_t)i) = o;
     *reinterpret_cast<uchar4*>(cls0 + 4 * (size_t)i) = o;
+    if (same) {
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, min(min(b0, b1), min(b2, b3)), max(max(b0, b1), max(b2, b3)));
+    } else {
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, b0, b0);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.y, s1, b1, b1);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.z, s2, b2, b2);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.w, s3, b3, b3);
+    }
   }
   // tail pixels when N is not a multiple of 4: straight to the global sums
   const int tail0 = n4 << 2;
   if (i < P.N - tail0) {
     const int p = tail0 + i;
-    const int root = S.parent[p];
+    const int root = mn_cc_root_ro(S.parent, p);
+    S.parent[p] = root;
+    S.lpvalid[p] = 0;
     float best = 0.0f;
     int b = 0;
     for (int c = 0; c < P.C; c++) {
@@ -356,8 +621,13 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     mn_cc_add(P, S, s_root, s_val, lp_acc, root, P.C, -1, 1);
     S.ocls[p] = (unsigned char)b;
     cls0[p] = (unsigned char)b;
+    mn_cc_cls(s_min, s_max, clsmin, clsmax, root, -1, b, b);
   }
   __syncthreads();
+  if (threadIdx.x < MN_CC_SUM_SLOTS && s_root[threadIdx.x] >= 0) {
+    atomicMin(&clsmin[s_root[threadIdx.x]], s_min[threadIdx.x]);
+    atomicMax(&clsmax[s_root[threadIdx.x]], s_max[threadIdx.x]);
+  }
   for (int j = threadIdx.x; j < nval; j += MN_CC_SUM_THREADS) {
     const u64 v = s_val[j];
     if (v == 0) continue;
@@ -387,25 +657,7 @@ __device__ __forceinline__ bool mn_tab_insert_bounded(const HashTab& T, u64 key,
   return false;
 }
 
-// Conditions (a), (b) on every edge; records between components summed into the table:
-// wave-aggregated by key, then collected in a per-block LDS table so that a record shared by the
-// whole boundary of a large instance costs one global insert per block.
-#define MN_CC_EDGE_THREADS 256   /* measured at 1024x2048: 1024 -> 52.1 us, 512 -> 49.7, 256 -> 47.3 */
-#define MN_CC_EDGE_G 5          /* offsets staged together: 3 -> 52.2 us, 5 -> 52.1, 10 -> 57.1 */
 #define MN_CC_EDGE_SLOTS 256
-__device__ __forceinline__ bool mn_cc_lds_add(u64* s_key, u64* s_sum, const HashTab& T, u64 key,
-                                              i64 s) {
-  unsigned h = (mn_hash(key) >> 7) & (MN_CC_EDGE_SLOTS - 1);
-#pragma unroll 1
-  for (int t = 0; t < 32; t++) {
-    u64 prev = s_key[h];                       // plain read first: the slot is usually there already
-    if (prev == MN_EMPTY) prev = atomicCAS(&s_key[h], MN_EMPTY, key);
-    if (prev == MN_EMPTY || prev == key) { atomicAdd(&s_sum[h], (u64)s); return true; }
-    h = (h + 1) & (MN_CC_EDGE_SLOTS - 1);
-  }
-  return mn_tab_insert_bounded(T, key, s);    // block table crowded: straight to the global one
-}
-
 // with the number of pixel edges per record alongside the sum (edge sweep of the fast certificate)
 __device__ __forceinline__ bool mn_cc_lds_add_cnt(u64* s_key, u64* s_sum, int* s_cnt, const HashTab& T,
                                                   int* __restrict__ tcount, u64 key, i64 s, int n) {
@@ -424,276 +676,156 @@ __device__ __forceinline__ bool mn_cc_lds_add_cnt(u64* s_key, u64* s_sum, int* s
   return mn_tab_insert_bounded(T, key, s, tcount, n);
 }
 
-__global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges(ImgParams P, ObjState S, HashTab T,
-                                                                  const unsigned char* __restrict__ cls0,
-                                                                  int* __restrict__ violations) {
-  __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
-  __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
-  if (threadIdx.x < MN_CC_EDGE_SLOTS) { s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; }
-  __syncthreads();
-  const int tile = mn_xcd_tile((P.N + MN_CC_EDGE_THREADS - 1) / MN_CC_EDGE_THREADS, P.banded);
-  const int p = tile < 0 ? P.N : tile * MN_CC_EDGE_THREADS + threadIdx.x;
-  const bool live = p < P.N;
-  int bad = 0, over = 0;
-  const int root = live ? S.parent[p] : 0;
-  if (live && cls0[p] != cls0[root]) bad++;                          // (c) one class per component
-  const int r = live ? p / P.W : 0, c0 = live ? p - r * P.W : 0;
-  // a pixel next to a boundary sees the same neighbouring component through most of its offsets:
-  // the lane sums its cross edges while the key stays the same and adds to the block table (LDS
-  // atomics) only when it changes
-  u64 ckey = MN_EMPTY;
-  i64 csum = 0;
-  constexpr int G = 10;                                 // offsets whose loads are in flight together
-  for (int k0 = 0; k0 < P.O; k0 += G) {
-    float v[G];
-    int rq[G];
-    bool in[G];
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      const int k = k0 + j;
-      in[j] = false;
-      v[j] = 0.5f;
-      rq[j] = root;
-      if (live && k < P.O) {
-        const int rr = r + P.di[k], cc = c0 + P.dj[k];
-        if (rr >= 0 && rr < P.H && cc >= 0 && cc < P.W) {
-          in[j] = true;
-          v[j] = P.same[(size_t)k * P.N + p];
-          rq[j] = S.parent[rr * P.W + cc];
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      if (!in[j]) continue;
-      // the gain omf * log-odds has the sign of v - 0.5 (the fixed-point log-odds of a float
-      // next to 0.5 are still 2^7 units); sep_hi / sep_lo widen 0.5 by the margin that keeps the
-      // float32 priority of a record strictly on its side of the bias (fill_params)
-      const float x = mn_same_value(P, v[j]);
-      if (rq[j] == root) { if (!(x >= P.sep_hi)) bad++; continue; }  // (a)
-      if (!(x <= P.sep_lo)) bad++;                                   // (b)
-      const u64 key = mn_key(root, rq[j]);
-      const i64 s = mn_edge_fixed(x);
-      if (key == ckey) { csum += s; continue; }
-      if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) over++;
-      ckey = key;
-      csum = s;
-    }
-  }
-  if (ckey != MN_EMPTY && !mn_cc_lds_add(s_key, s_sum, T, ckey, csum)) over++;
-  __syncthreads();
-  if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
-    if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x])) over++;
-  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
-  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
-  if (over) atomicAdd(violations + 1, over);   // table full: not a verdict on the maps
-}
 
-// The same sweep with 4 consecutive pixels of one row per lane (W % 4 == 0): the sameness values
-// come as one 16-byte load per offset, the four neighbour roots as one (unaligned) 16-byte load,
-// and a lane next to a boundary folds up to 40 cross edges into its running sum before it touches
-// the block table.
-struct __attribute__((packed, aligned(4))) mn_int4u { int x, y, z, w; };
-__device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) {
-  const mn_int4u t = *reinterpret_cast<const mn_int4u*>(p);
-  return make_int4(t.x, t.y, t.z, t.w);
-}
-
-// This sweep also lays the ground for the certificate and the log-likelihood of the final
-// partition, so that no further sweep over the sameness planes is needed after the merge
-// (mn_cc_certificate): per block the float64 sums  sum log v  over edges inside components and
-// sum log(1-v)  over edges between components (partial[2b], partial[2b+1]), and per record the
-// number of pixel edges folded into it (tcount, parallel to the table).
-__global__ __launch_bounds__(MN_CC_EDGE_THREADS) void mn_cc_edges4(ImgParams P, ObjState S, HashTab T,
-                                                                   const unsigned char* __restrict__ cls0,
-                                                                   int* __restrict__ violations,
-                                                                   int* __restrict__ tcount,
-                                                                   double* __restrict__ partial) {
+// ---- records between components from the negative-edge list -------------------------------------
+// Every entry is an in-bounds edge with value <= sep_lo.  Both ends in one component: condition (a)
+// fails (a negative edge inside a component).  Otherwise its log-odds (2^-30 fixed point, the same
+// value mn_edge_fixed gives) go to the record of the two components: block table in LDS first --
+// the entries of a block come from neighbouring pixels and share a handful of records -- then one
+// bounded insert per record and block into the global table, with the number of pixel edges
+// alongside (certificate).  parent[] is flat here.
+#define MN_CC_CROSS_THREADS 256
+#define MN_CC_CROSS_CHUNK 2048
+__global__ __launch_bounds__(MN_CC_CROSS_THREADS) void mn_cc_cross(
+    ImgParams P, const int* __restrict__ parent, HashTab T, const u64* __restrict__ neg_list,
+    const unsigned* __restrict__ neg_count, unsigned sub_cap, int* __restrict__ violations,
+    int* __restrict__ tcount) {
+  // one block per block of the sign sweep: its region of the list, its count
+  const unsigned n = min(neg_count[blockIdx.x], sub_cap);
+  if (n == 0) return;                                                  // uniform
   __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
   __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
   __shared__ int s_cnt[MN_CC_EDGE_SLOTS];
-  __shared__ double s_part[2][MN_CC_EDGE_THREADS / 64];
   if (threadIdx.x < MN_CC_EDGE_SLOTS) {
     s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
   }
   __syncthreads();
-  double t_same = 0.0, t_diff = 0.0;
-  int ccnt = 0;
-  const int n4 = P.N >> 2;
-  const int i = blockIdx.x * MN_CC_EDGE_THREADS + threadIdx.x;
-  const bool live = i < n4;
-  const int p0 = live ? 4 * i : 0;
+  const u64* __restrict__ list = neg_list + (size_t)blockIdx.x * sub_cap;
+  const int lane = threadIdx.x & 63;
   int bad = 0, over = 0;
-  const int r = p0 / P.W, c0 = p0 - r * P.W;
-  int root0 = 0, root1 = 0, root2 = 0, root3 = 0;
-  if (live) {
-    const int4 rv = *reinterpret_cast<const int4*>(S.parent + p0);
-    root0 = rv.x; root1 = rv.y; root2 = rv.z; root3 = rv.w;
-    const uchar4 own = *reinterpret_cast<const uchar4*>(cls0 + p0);
-    bad += (own.x != cls0[root0]) + (own.y != cls0[root1]) +         // (c) one class per component
-           (own.z != cls0[root2]) + (own.w != cls0[root3]);
-  }
-  u64 ckey = MN_EMPTY;
-  i64 csum = 0;
-  constexpr int G = MN_CC_EDGE_G;                                  // offsets whose loads are in flight together
-  for (int k0 = 0; k0 < P.O; k0 += G) {
-    float4 v[G];
-    int4 rq[G];
-    int first[G];                                       // column of the first neighbour, or INT_MIN
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      const int k = k0 + j;
-      first[j] = INT_MIN;
-      if (live && k < P.O) {
-        const int rr = r + P.di[k];
-        if (rr >= 0 && rr < P.H) {
-          first[j] = c0 + P.dj[k];
-          v[j] = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
-          const long long q0 = (long long)rr * P.W + first[j];
-          if (q0 >= 0 && q0 + 3 < P.N) {
-            rq[j] = mn_ld_int4_unaligned(S.parent + q0);
-          } else {                                      // first / last pixels of the image
-            rq[j].x = (q0 >= 0 && q0 < P.N) ? S.parent[q0] : 0;
-            rq[j].y = (q0 + 1 >= 0 && q0 + 1 < P.N) ? S.parent[q0 + 1] : 0;
-            rq[j].z = (q0 + 2 >= 0 && q0 + 2 < P.N) ? S.parent[q0 + 2] : 0;
-            rq[j].w = (q0 + 3 >= 0 && q0 + 3 < P.N) ? S.parent[q0 + 3] : 0;
-          }
+  for (unsigned base = 0; base < n; base += MN_CC_CROSS_CHUNK) {
+    for (unsigned t0 = 0; t0 < MN_CC_CROSS_CHUNK; t0 += MN_CC_CROSS_THREADS) {
+      const unsigned idx = base + t0 + threadIdx.x;
+      if (base + t0 >= n) break;                                       // uniform
+      u64 key = MN_EMPTY;
+      i64 sx = 0;
+      if (idx < n) {
+        const u64 e = list[idx];
+        const unsigned edge = (unsigned)(e >> 32);
+        const int k = (int)(edge >> MN_CC_EDGE_PIXBITS), p = (int)(edge & ((1u << MN_CC_EDGE_PIXBITS) - 1u));
+        const int q = p + P.di[k] * P.W + P.dj[k];
+        const int ru = parent[p], rv = parent[q];
+        if (ru == rv) bad++;                                           // (a)
+        else {
+          key = mn_key(ru, rv);
+          const float oml = __uint_as_float((unsigned)(e & 0xFFFFFFFFull));
+          sx = __float2ll_rn(oml * (float)MN_FIX_ONE);                  // = mn_edge_fixed(value)
         }
       }
-    }
-    auto edge = [&](int col, float raw, int q, int own) {
-      if (col < 0 || col >= P.W) return;
-      const float x = mn_same_value(P, raw);                         // margins: see mn_cc_edges
-      if (q == own) {                                                // (a)
-        if (!(x >= P.sep_hi)) bad++;
-        t_same += (double)logf(x);
-        return;
+      // neighbouring entries come from neighbouring pixels: a wave often holds ONE record, and 64
+      // LDS atomics on one address would run one after the other -- reduce in the wave instead
+      const u64 k0 = ((u64)(unsigned)__shfl((int)(key >> 32), 0) << 32) | (u64)(unsigned)__shfl((int)(key & 0xFFFFFFFFull), 0);
+      if (__ballot(key != k0) == 0) {
+        if (k0 == MN_EMPTY) continue;
+        i64 tot = sx;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0 && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, k0, tot, 64)) over++;
+      } else if (key != MN_EMPTY) {
+        if (!mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, key, sx, 1)) over++;
       }
-      if (!(x <= P.sep_lo)) bad++;                                   // (b)
-      const u64 key = mn_key(own, q);
-      const float ld = mn_log1m(x);
-      t_diff += (double)ld;
-      const i64 sx = __float2ll_rn((logf(x) - ld) * (float)MN_FIX_ONE);   // = mn_edge_fixed(x)
-      if (key == ckey) { csum += sx; ccnt++; return; }
-      if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) over++;
-      ckey = key;
-      csum = sx;
-      ccnt = 1;
-    };
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      if (first[j] == INT_MIN) continue;
-      edge(first[j], v[j].x, rq[j].x, root0);
-      edge(first[j] + 1, v[j].y, rq[j].y, root1);
-      edge(first[j] + 2, v[j].z, rq[j].z, root2);
-      edge(first[j] + 3, v[j].w, rq[j].w, root3);
     }
-  }
-  if (ckey != MN_EMPTY && !mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, ckey, csum, ccnt)) over++;
-  for (int off = 32; off > 0; off >>= 1) {
-    bad += __shfl_xor(bad, off);
-    t_same += __shfl_xor(t_same, off);
-    t_diff += __shfl_xor(t_diff, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (bad) atomicAdd(violations, bad);
-    s_part[0][threadIdx.x >> 6] = t_same;
-    s_part[1][threadIdx.x >> 6] = t_diff;
   }
   __syncthreads();
-  int late = 0;
   if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
     if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x], tcount, s_cnt[threadIdx.x]))
-      late = 1;
-  if (late || over) atomicAdd(violations + 1, late + over);   // table full: not a verdict on the maps
-  if (threadIdx.x < 2) {                                // block order: the sum is reproducible
-    double t = 0.0;
-    for (int w = 0; w < MN_CC_EDGE_THREADS / 64; w++) t += s_part[threadIdx.x][w];
-    partial[(size_t)blockIdx.x * 2 + threadIdx.x] = t;
-  }
-}
-
-// After the merge: what the sweeps above could not know.  One lane per pixel, work only at the
-// component roots (compsize > 0): the class term of the log-likelihood  lp[cls]  of every final
-// object, and the pixels whose own arg-max class differs from their final object's class (a
-// component has one class, so that is the component's size or nothing).
-#define MN_CC_CERT_THREADS 1024
-__global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(ImgParams P, ObjState S,
-                                                         const unsigned char* __restrict__ cls0,
-                                                         const int* __restrict__ compsize,
-                                                         double* __restrict__ partial_cls,
-                                                         int* __restrict__ violations) {
-  __shared__ double sh[MN_CC_CERT_THREADS / 64];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  double t_cls = 0.0;
-  int bad_cls = 0;
-  if (p < P.N) {
-    const int cs = compsize[p];
-    if (cs > 0) {
-      int f = p;
-      while (S.parent[f] != f) f = S.parent[f];
-      const int oc = S.ocls[f];
-      if (cls0[p] != oc) bad_cls = cs;
-      if (f == p) t_cls = (double)mn_obj_lp(P, S, S.lpvalid[p] != 0, p, oc);
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    t_cls += __shfl_xor(t_cls, off);
-    bad_cls += __shfl_xor(bad_cls, off);
-  }
+      over++;
+  for (int off = 32; off > 0; off >>= 1) { bad += __shfl_xor(bad, off); over += __shfl_xor(over, off); }
   if ((threadIdx.x & 63) == 0) {
-    sh[threadIdx.x >> 6] = t_cls;
-    if (bad_cls) atomicAdd(violations + 3, bad_cls);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < MN_CC_CERT_THREADS / 64; w++) t += sh[w];
-    partial_cls[blockIdx.x] = t;
+    if (bad) atomicAdd(violations, bad);
+    if (over) atomicAdd(violations + 1, over);       // table full: not a verdict on the maps
   }
 }
 
-// total = class term + omf * (sum over edges: log v inside final objects, log(1-v) between them).
-// The edge sweep summed it for the components; a record merged afterwards moves its edges from
-// "between" to "inside", i.e. adds its log-odds sum, and makes each of them an edge whose sign
-// contradicts the partition (the finisher accumulated both).
-__global__ __launch_bounds__(256) void mn_cc_cert_reduce(int nb_edges, const double* __restrict__ partial_edges,
-                                                         int nb_cls, const double* __restrict__ partial_cls,
-                                                         const Counters* __restrict__ cnt, float omf,
-                                                         double* __restrict__ out,
-                                                         int* __restrict__ violations) {
-  __shared__ double sh[3][256];
-  double a[3] = {0.0, 0.0, 0.0};
-  for (int b = threadIdx.x; b < nb_cls; b += 256) a[0] += partial_cls[b];
-  for (int b = threadIdx.x; b < nb_edges; b += 256) {
-    a[1] += partial_edges[(size_t)b * 2];
-    a[2] += partial_edges[(size_t)b * 2 + 1];
-  }
-  for (int j = 0; j < 3; j++) sh[j][threadIdx.x] = a[j];
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off)
-      for (int j = 0; j < 3; j++) sh[j][threadIdx.x] += sh[j][threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const double moved = (double)cnt->merged_S * (1.0 / MN_FIX_ONE);
-    out[0] = sh[0][0] + ((sh[2][0] + sh[1][0]) + moved) * (double)omf;
-    out[1] = sh[0][0]; out[2] = sh[1][0]; out[3] = sh[2][0];
-    if (cnt->merged_E) atomicAdd(violations, cnt->merged_E);
-  }
-}
-
+// fixed-point sums -> object state; condition (c); the list of component roots (for the
+// certificate, which then needs no pass over the pixels)
 __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
                                                     const i64* __restrict__ lp_acc,
-                                                    int* __restrict__ compsize) {
+                                                    const int* __restrict__ clsmin,
+                                                    const int* __restrict__ clsmax,
+                                                    int* __restrict__ compsize,
+                                                    int* __restrict__ rootlist,
+                                                    int* __restrict__ nroots,
+                                                    int* __restrict__ violations) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool is_root = p < P.N && S.parent[p] == p;
+  const u64 m = __ballot(is_root);
+  if (m) {                                  // wave-aggregated append (roots are few)
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(nroots, __popcll(m));
+    base = __shfl(base, leader);
+    if (is_root) rootlist[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+  }
   if (p >= P.N) return;
-  const bool is_root = S.parent[p] == p;
-  compsize[p] = is_root ? S.osize[p] : 0;  // kept for mn_cc_certificate: osize grows in the merge
+  compsize[p] = is_root ? S.osize[p] : 0;  // kept for the certificate: osize grows in the merge
   if (!is_root) return;
+  if (clsmin[p] != clsmax[p]) atomicAdd(violations, 1);                // (c) one class per component
   if (S.osize[p] <= 1) return;            // a lone pixel keeps reading its class planes
   for (int c = 0; c < P.C; c++)
     S.lpsum[(size_t)c * P.N + p] = (float)((double)lp_acc[(size_t)c * P.N + p] * (1.0 / MN_LP_FIX));
   S.lpvalid[p] = 1;
+}
+
+// ---- certificate and log-likelihood after the merge, without another sweep ----------------------
+// total = class term + omf * (sum over edges: log v inside final objects, log(1-v) between them).
+// The sign sweep summed both for the components (per block, float64); a record merged afterwards
+// moves its edges from "between" to "inside", i.e. adds its log-odds sum, and makes each of them an
+// edge whose sign contradicts the partition (the finisher accumulated both).  What is left is per
+// COMPONENT: the class term lp[cls] of every final object and the pixels whose own arg-max class
+// differs from their final object's class (a component has one class: its size or nothing).  One
+// workgroup walks the root list; the class term is summed in 2^-32 fixed point, so the order in
+// which the roots were appended does not show in the result.
+#define MN_CC_CERT_THREADS 1024
+__global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(
+    ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ compsize,
+    const int* __restrict__ rootlist, const int* __restrict__ nroots, int nb_edges,
+    const double* __restrict__ partial_edges, const Counters* __restrict__ cnt,
+    double* __restrict__ out, int* __restrict__ violations) {
+  __shared__ double sh[2][MN_CC_CERT_THREADS];
+  __shared__ u64 s_cls;
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) { s_cls = 0; s_bad = 0; }
+  __syncthreads();
+  const int n = *nroots;
+  i64 t_cls = 0;
+  int bad_cls = 0;
+  for (int j = threadIdx.x; j < n; j += MN_CC_CERT_THREADS) {
+    const int p = rootlist[j];
+    int f = p;
+    while (S.parent[f] != f) f = S.parent[f];
+    const int oc = S.ocls[f];
+    if (cls0[p] != oc) bad_cls += compsize[p];
+    if (f == p) t_cls += __float2ll_rn(mn_obj_lp(P, S, S.lpvalid[p] != 0, p, oc) * 4294967296.0f);
+  }
+  if (t_cls) atomicAdd(&s_cls, (u64)t_cls);
+  if (bad_cls) atomicAdd(&s_bad, bad_cls);
+  double a0 = 0.0, a1 = 0.0;
+  for (int b = threadIdx.x; b < nb_edges; b += MN_CC_CERT_THREADS) {
+    a0 += partial_edges[(size_t)b * 2];
+    a1 += partial_edges[(size_t)b * 2 + 1];
+  }
+  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int off = MN_CC_CERT_THREADS / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cls_term = (double)(i64)s_cls * (1.0 / MN_LP_FIX);
+    const double moved = (double)cnt->merged_S * (1.0 / MN_FIX_ONE);
+    out[0] = cls_term + ((sh[1][0] + sh[0][0]) + moved) * (double)P.omf;
+    out[1] = cls_term; out[2] = sh[0][0]; out[3] = sh[1][0];
+    if (cnt->merged_E) atomicAdd(violations, cnt->merged_E);
+    if (s_bad) atomicAdd(violations + 3, s_bad);
+  }
 }

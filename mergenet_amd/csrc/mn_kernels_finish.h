@@ -254,7 +254,10 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     unsigned w = 0, u = DEAD, v = DEAD;
     if (i < R) {
       const u64 k = L.key[i];
-      if (k != MN_EMPTY) { u = (unsigned)mn_key_u(k); v = (unsigned)mn_key_v(k); w = mn_fin_word(L.st[i]); }
+      if (k != MN_EMPTY) {
+        u = (unsigned)mn_key_u(k); v = (unsigned)mn_key_v(k); w = mn_fin_word(L.st[i]);
+        maprec[u] = -1; maprec[v] = -1;     // the (object -> record) map is only ever read at
+      }                                     // endpoints of records: no N-sized clear beforehand
     }
     lw[i] = w; lu[i] = u; lv[i] = v;
   }

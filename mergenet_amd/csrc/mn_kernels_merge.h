@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
     L.fr[idx] = f;
     L.aux[idx] = (unsigned char)((mc & 0x7F) | (pos ? 0x80 : 0));
     if (lcount) lcount[idx] = tcount[slot];           // pixel edges per record (components mode)
-    if (st >= 0.0f) {
+    if (ball && st >= 0.0f) {                         // (no best-record slots: the finisher takes the list)
       // a plain look first: most records lose against what is already there (an object has tens
       // of records, a running maximum changes ~ln(n) times), and a lost race only costs the atomic
       const u64 ku = mn_pack(st, v, pos), kv = mn_pack(st, u, pos);
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
     }
   }
   // highest visible priority of the round (for the band threshold), spread over 64 words
+  if (!ball) return;
   for (int off = 32; off > 0; off >>= 1) mybits = max(mybits, (unsigned)__shfl_xor((int)mybits, off));
   if (lane == 0 && mybits) atomicMax(&gmax[(blockIdx.x * 4 + wave) & 63], mybits);
 }

@@ -60,7 +60,7 @@ class MnStats(ctypes.Structure):
                 ("ms_edge_pass", ctypes.c_float), ("ms_merge", ctypes.c_float),
                 ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
-                ("ms_cc_edges", ctypes.c_float), ("ms_reserved", ctypes.c_float),
+                ("ms_cc_edges", ctypes.c_float), ("ms_cc_cross", ctypes.c_float),
                 ("proof", ctypes.c_int), ("reserved_i", ctypes.c_int * 3)]
 
     def as_dict(self) -> dict:

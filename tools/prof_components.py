@@ -1,7 +1,7 @@
 """Whole merger in the default mode, repeated with cold caches (for rocprofv3 --pmc / --kernel-trace
 on the GPU box): python tools/prof_components.py [n]."""
-import sys
-sys.path.insert(0, '.')
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mergenet_amd import synth, segmenter as seg
 H, W = 1024, 2048
@@ -16,6 +16,6 @@ tot = 0.0
 for it in range(n):
     scratch.fill_(float(it))
     torch.cuda.synchronize()
-    _, _, _, st = m.segment(cp, sp, offs, seg.default_options())
+    _, _, _, st = m.segment(cp, sp, offs, seg.default_options(mode=int(os.environ.get('MN_PROF_MODE', '0'))))
     tot += st["ms_total"]
 print("mode_used %d, avg device time %.3f ms per image (cold caches)" % (st["mode_used"], tot / n))
