@@ -18,6 +18,7 @@
 #include "mn_kernels_output.h"
 #include "mn_kernels_prepare.h"
 #include "mn_kernels_cc.h"
+#include "mn_kernels_tail.h"
 
 // Counters | 16 int scalars | 4 doubles, each part 16-byte aligned
 // scalars: [0] edge violations [1] instances [2] objects [3] class violations [4] record violations
@@ -58,7 +59,7 @@ struct mn_context {
   RecList LA, LB;
   int* touched_list;
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
-  int fin_lds_ready;
+  int fin_lds_ready, tail_lds_ready;
   HashTab T;
   // output / scratch
   int* block_count;
@@ -101,6 +102,8 @@ struct mn_context {
     mn_stats stats;
   } pend;
   hipEvent_t ev_done;
+  hipStream_t side;       // the single-workgroup tail of an image runs here, beside the next image's sweeps
+  hipEvent_t ev_fork;
   ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
   int last_valid;
   // staging for the host-pointer entry points
@@ -214,6 +217,8 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
   for (int i = 0; i < 12; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  MN_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  MN_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   return MN_OK;
 }
 
@@ -258,6 +263,8 @@ extern "C" void mn_destroy(mn_context* c) {
   for (int i = 0; i < 12; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->side) (void)hipStreamDestroy(c->side);
   free(c);
 }
 
@@ -484,7 +491,8 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
   }
 }
 
-static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait, bool with_ball) {
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait, bool with_ball,
+                          bool with_compact) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256);
@@ -509,7 +517,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   int* clsmin = c->root;
   int* clsmax = c->mapbuf;
   hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv,
-                     c->osize, c->lp_acc, clsmin, clsmax);
+                     c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
   if (kh >= 0 || kv >= 0) {
     hipLaunchKernelGGL(mn_cc_borders, tiles, dim3(128), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv);
@@ -529,13 +537,17 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
     if (lds > c->cc_sum_lds) {
-      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums),
+      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums<0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       c->cc_sum_lds = lds;
     }
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
-    hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
-                       c->lp_acc, clsmin, clsmax);
+    if (P.C == 9)           // the Cityscapes class count (egs/cityscape/local/segment.py:38)
+      hipLaunchKernelGGL(mn_cc_class_sums<9>, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
+                         c->lp_acc, clsmin, clsmax);
+    else
+      hipLaunchKernelGGL(mn_cc_class_sums<0>, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
+                         c->lp_acc, clsmin, clsmax);
   }
   MN_HIP(hipEventRecord(c->ev[8], st));
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
@@ -545,12 +557,14 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
-  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for(N, 256)), b, 0, st, P, S, (const i64*)c->lp_acc,
+  hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for((size_t)(N >> 4) > 0 ? (size_t)(N >> 4) : 1, 256)), b, 0, st, P, S,
+                     (const unsigned char*)c->matched, (const i64*)c->lp_acc,
                      (const int*)clsmin, (const int*)clsmax, c->mate, c->cc_roots, c->scalars + 8,
                      c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
-  hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
-                     T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
-                     (const int*)c->cc_tcount, c->cc_lcount);
+  if (with_compact)                // (mn_cc_tail takes the table itself)
+    hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
+                       T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
+                       (const int*)c->cc_tcount, c->cc_lcount);
   MN_HIP(hipGetLastError());
   if (!wait) return 0;             // speculative: the caller finds out at its final synchronisation
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, MN_NSCALARS * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -661,6 +675,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     mode = MN_MODE_ROUNDS;
   ObjState S = obj_state(c);
 
+  bool fused_tail = false;         // the speculative attempt of the C++ variant ends in mn_cc_tail
   FillList fills;
   fills.add(c->cnt, sizeof(Counters), 0);
   fills.add(c->scalars, MN_NSCALARS * sizeof(int), 0);
@@ -673,7 +688,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     // most finish_limit of them, takes a table of 8x that many slots (less to clear, less for
     // mn_compact to scan); the ordinary attempt one of N/8.  A table that fills up fails the
     // bounded insert, counted apart from the separability violations (scalars[7]).
-    size_t cap = speculate ? next_pow2((size_t)finish_limit * 8) : next_pow2((size_t)N / 8 + 8192);
+    // (the speculative attempt ends in mn_cc_tail, whose lanes hold MN_TAIL_TABLE_CAP / 1024 slots each)
+    fused_tail = speculate && opts->variant == MN_VARIANT_CSEGMENT;
+    size_t cap = fused_tail ? (size_t)MN_TAIL_TABLE_CAP
+                            : (speculate ? next_pow2((size_t)finish_limit * 8) : next_pow2((size_t)N / 8 + 8192));
     if (cap > c->cc_cap_max) cap = c->cc_cap_max;
     c->cc_cap = cap;
     fills.add(c->T.key, cap * sizeof(u64), 0xFF);
@@ -693,7 +711,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
-    rc = run_components(c, P, st, !speculate, !speculate);
+    rc = run_components(c, P, st, !speculate, !speculate, !fused_tail);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
@@ -764,8 +782,31 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       if (selected == 0) break;     // nothing visible any more: the queue is empty
     }
   }
+  const bool want_cert = opts->compute_logprob != 0;
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
-  {
+  if (fused_tail) {
+    // From here on the image is one workgroup's work (and one pixel-wide mask write): it moves to
+    // the context's side stream, so that the sweeps of the NEXT image (another context, the
+    // caller's stream) run beside it instead of behind it.  mn_segment_finish waits for the side
+    // stream; nothing of this image is left on the caller's stream after this point.
+    MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    st = c->side;
+    if (!c->tail_lds_ready) {
+      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_tail),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, MN_FIN2_MAXR * 12));
+      c->tail_lds_ready = 1;
+    }
+    HashTab T = c->T;
+    T.mask = (unsigned)(c->cc_cap - 1);
+    const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
+    const int nbe = (int)grid_for((size_t)(P.W % 4 == 0 ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+    hipLaunchKernelGGL(mn_cc_tail, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S, T,
+                       (const int*)c->cc_tcount, cur, c->cc_lcount, c->label, c->fin_lists, c->cnt, max_steps,
+                       c->scalars, finish_limit, (const unsigned char*)c->cls0, (const int*)c->mate,
+                       (const int*)c->cc_roots, nbe, (const double*)c->partial, c->lp_out, want_cert ? 1 : 0,
+                       c->label, d_object_class);
+  } else {
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
     // (records that come straight from the component contraction were scored a moment ago)
     if (mode != MN_MODE_EXACT && R > 0 && !opts->no_handover_refresh &&
@@ -802,19 +843,20 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                        opts->prune_threshold, (const u64*)c->bg_key, c->pruned, c->cnt);
     pruned = c->pruned;
   }
-  const int nblk = (int)grid_for(N, MN_SCAN_ITEMS);
-  hipLaunchKernelGGL(mn_rank_count, dim3(nblk), dim3(256), 0, st, N, S, pruned, c->block_count,
-                     c->scalars + 2);
-  hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 1);
-  hipLaunchKernelGGL(mn_rank_assign, dim3(nblk), dim3(256), 0, st, N, S, pruned,
-                     (const int*)c->block_count, c->label, d_object_class);
+  if (!fused_tail) {
+    const int nblk = (int)grid_for(N, MN_SCAN_ITEMS);
+    hipLaunchKernelGGL(mn_rank_count, dim3(nblk), dim3(256), 0, st, N, S, pruned, c->block_count,
+                       c->scalars + 2);
+    hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 1);
+    hipLaunchKernelGGL(mn_rank_assign, dim3(nblk), dim3(256), 0, st, N, S, pruned,
+                       (const int*)c->block_count, c->label, d_object_class);
+  }
   hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
                      (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
                      c->root, d_mask, d_partition, d_object_class);
   // certificate + log-likelihood (skipped on request: compute_logprob = 0, the drop-in entry's
   // setting -- the reference's c_run_segmentation returns neither)
-  const bool want_cert = opts->compute_logprob != 0;
-  if (!want_cert) {
+  if (!want_cert || fused_tail) {
   } else if (mode == MN_MODE_COMPONENTS && rounds == 0 && R <= MN_FIN2_MAXR) {
     // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
     // for the components and the finisher what the merged records moved (mn_cc_certificate)

@@ -40,7 +40,10 @@
 #include "mn_device.h"
 #include "mn_kernels_merge.h"
 
-#define MN_LP_FIX 4294967296.0   /* 2^32: fixed-point scale of class log-prob sums */
+#define MN_LP_FIX 16777216.0     /* 2^24: fixed-point scale of class log-prob sums.  |log p| <= 16, so a
+                                    value fits an int32 (ONE v_cvt_i32_f32; a float -> int64 conversion
+                                    is a dozen instructions and the sweep is VALU-bound), four of them
+                                    still do, and 2^-24 is finer than a float log of magnitude >= 0.5 */
 
 __device__ __forceinline__ int mn_cc_find(int* __restrict__ parent, int x) {
   int p = parent[x];
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
 __global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, const unsigned* __restrict__ bits,
                                                     int* __restrict__ parent, int kh, int kv, int dv,
                                                     int* __restrict__ osize, i64* __restrict__ lp_acc,
-                                                    int* __restrict__ clsmin, int* __restrict__ clsmax) {
+                                                    int* __restrict__ clsmin, int* __restrict__ clsmax,
+                                                    unsigned char* __restrict__ cand) {
   __shared__ int lab[MN_CC_TILE_ROWS * 64];
   const int t = threadIdx.x, lane = t & 63, i = t >> 6;
   const int r = (int)blockIdx.y * MN_CC_TILE_ROWS + i, c = (int)blockIdx.x * 64 + lane;
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, const unsigned*
   while (lab[x] != x) x = lab[x];
   parent[p] = ((int)blockIdx.y * MN_CC_TILE_ROWS + (x >> 6)) * P.W + (int)blockIdx.x * 64 + (x & 63);
   osize[p] = 0;
+  cand[p] = (x == t) ? 1 : 0;               // the only pixels that can be a component root
   if (x == t) {
     for (int c = 0; c < P.C; c++) lp_acc[(size_t)c * P.N + p] = 0;
     clsmin[p] = 255;
@@ -520,6 +525,21 @@ __device__ __forceinline__ void mn_cc_cls(int* s_min, int* s_max, int* __restric
   }
 }
 
+// first maximum of logf over the classes of one pixel (Object::Object, segment.cc:5-21)
+__device__ __forceinline__ int mn_cc_argmax_logf(const ImgParams& P, int p) {
+  float best = 0.0f;
+  int b = 0;
+  for (int c = 0; c < P.C; c++) {
+    const float l = logf(mn_ld_class(P, c, p));
+    if (c == 0 || l > best) { best = l; b = c; }
+  }
+  return b;
+}
+
+// CT > 0: compile-time class count, ALL class planes of the lane are requested before the first is
+// used (one HBM round trip per wave instead of C: the grid is a single residency of the chip, so a
+// wave's dependent chain is the kernel's duration).  CT == 0: any class count, one plane ahead.
+template <int CT>
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc,
     int* __restrict__ clsmin, int* __restrict__ clsmax) {
@@ -548,41 +568,65 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     const int s1 = same ? s0 : mn_lds_root_slot(s_root, r.y);
     const int s2 = same ? s0 : mn_lds_root_slot(s_root, r.z);
     const int s3 = same ? s0 : mn_lds_root_slot(s_root, r.w);
-    float4 best;
+    // The sweep is VALU-bound if every value takes a libm log (36 per lane, ~22 instructions each):
+    //  * the arg-max is taken on the VALUES (logf is monotone); the reference's first-maximum rule
+    //    on logf values differs only if a class of LOWER index lies within rounding distance of the
+    //    maximum (logf may map both to one float) -- `prev` keeps the largest value below the
+    //    current best's index and such pixels redo their arg-max with logf (mn_cc_argmax_logf);
+    //  * a lane whose four pixels share a component -- nearly all -- adds  log(v0 v1 v2 v3)  per
+    //    class: ONE log instead of four (values >= 2^-23 after the binding's clip, so the product
+    //    stays above 2^-92; relative error 2e-7, far below the float32 accumulation it replaces).
+    float4 best, prev = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
     int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     // the next plane's load is issued before this plane's values are used (one extra float4 of
     // registers: the kernel stays at two 1024-thread blocks per CU, which matters more here than
     // deeper staging -- three planes in flight at 85 VGPRs measured slower)
-    float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
-    for (int c = 0; c < P.C; c++) {
-      {
-        float4 v = nxt;
+    float4 stage[CT > 0 ? CT : 1];
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CT > 0) {
+#pragma unroll
+      for (int c = 0; c < CT; c++)
+        stage[c] = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)i);
+    } else {
+      nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
+    }
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : P.C); c++) {
+      float4 v;
+      if (CT > 0) {
+        v = stage[c];
+      } else {
+        v = nxt;
         if (c + 1 < P.C)
           nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
-        if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
-        float4 l;
-        l.x = logf(v.x); l.y = logf(v.y); l.z = logf(v.z); l.w = logf(v.w);
-        if (c == 0) {
-          best = l;
-        } else {
-          if (l.x > best.x) { best.x = l.x; b0 = c; }
-          if (l.y > best.y) { best.y = l.y; b1 = c; }
-          if (l.z > best.z) { best.z = l.z; b2 = c; }
-          if (l.w > best.w) { best.w = l.w; b3 = c; }
-        }
-        // float * 2^32 is exact, so each term is the double-precision product rounded to nearest
-        const i64 f0 = __float2ll_rn(l.x * 4294967296.0f), f1 = __float2ll_rn(l.y * 4294967296.0f);
-        const i64 f2 = __float2ll_rn(l.z * 4294967296.0f), f3 = __float2ll_rn(l.w * 4294967296.0f);
-        if (same) {
-          mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (f0 + f1) + (f2 + f3));
-        } else {
-          mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, f0);
-          mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, f1);
-          mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, f2);
-          mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, f3);
-        }
+      }
+      if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
+      if (c == 0) {
+        best = v;
+      } else {
+        if (v.x > best.x) { prev.x = best.x; best.x = v.x; b0 = c; }
+        if (v.y > best.y) { prev.y = best.y; best.y = v.y; b1 = c; }
+        if (v.z > best.z) { prev.z = best.z; best.z = v.z; b2 = c; }
+        if (v.w > best.w) { prev.w = best.w; best.w = v.w; b3 = c; }
+      }
+      // float * 2^24 is exact, so each term is the exact product rounded to the nearest integer
+      if (same) {
+        const float l = logf((v.x * v.y) * (v.z * v.w));
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (i64)__float2int_rn(l * (float)MN_LP_FIX));
+      } else {
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (i64)__float2int_rn(logf(v.x) * (float)MN_LP_FIX));
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, (i64)__float2int_rn(logf(v.y) * (float)MN_LP_FIX));
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, (i64)__float2int_rn(logf(v.z) * (float)MN_LP_FIX));
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, (i64)__float2int_rn(logf(v.w) * (float)MN_LP_FIX));
       }
     }
+    // a lower class within 2^-18 of the maximum (logs of magnitude < 16 are 2^-20 apart at most, and
+    // the GPU's logf is within an ulp of libm's): settle it the reference's way
+    const float near = 1.0f - 3.814697265625e-06f;
+    if (prev.x >= best.x * near) b0 = mn_cc_argmax_logf(P, 4 * i);
+    if (prev.y >= best.y * near) b1 = mn_cc_argmax_logf(P, 4 * i + 1);
+    if (prev.z >= best.z * near) b2 = mn_cc_argmax_logf(P, 4 * i + 2);
+    if (prev.w >= best.w * near) b3 = mn_cc_argmax_logf(P, 4 * i + 3);
     if (same) {
       mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
     } else {
@@ -616,7 +660,7 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     for (int c = 0; c < P.C; c++) {
       const float l = logf(mn_ld_class(P, c, p));
       if (c == 0 || l > best) { best = l; b = c; }
-      mn_cc_add(P, S, s_root, s_val, lp_acc, root, c, -1, __float2ll_rn(l * 4294967296.0f));
+      mn_cc_add(P, S, s_root, s_val, lp_acc, root, c, -1, (i64)__float2int_rn(l * (float)MN_LP_FIX));
     }
     mn_cc_add(P, S, s_root, s_val, lp_acc, root, P.C, -1, 1);
     S.ocls[p] = (unsigned char)b;
@@ -747,8 +791,27 @@ __global__ __launch_bounds__(MN_CC_CROSS_THREADS) void mn_cc_cross(
 }
 
 // fixed-point sums -> object state; condition (c); the list of component roots (for the
-// certificate, which then needs no pass over the pixels)
+// certificate and the labels, which then need no pass over the pixels).  Only tile roots can be
+// component roots: a lane reads the candidate flags of 16 pixels (N bytes in all) and nearly all
+// lanes stop there.
+__device__ __forceinline__ void mn_cc_finish_root(const ImgParams& P, const ObjState& S, int p,
+                                                  const i64* __restrict__ lp_acc,
+                                                  const int* __restrict__ clsmin,
+                                                  const int* __restrict__ clsmax,
+                                                  int* __restrict__ compsize, int* __restrict__ rootlist,
+                                                  int* __restrict__ nroots, int* __restrict__ violations) {
+  if (S.parent[p] != p) return;
+  rootlist[atomicAdd(nroots, 1)] = p;     // (component roots are few)
+  compsize[p] = S.osize[p];               // kept for the certificate: osize grows in the merge
+  if (clsmin[p] != clsmax[p]) atomicAdd(violations, 1);                // (c) one class per component
+  if (S.osize[p] <= 1) return;            // a lone pixel keeps reading its class planes
+  for (int c = 0; c < P.C; c++)
+    S.lpsum[(size_t)c * P.N + p] = (float)((double)lp_acc[(size_t)c * P.N + p] * (1.0 / MN_LP_FIX));
+  S.lpvalid[p] = 1;
+}
+
 __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
+                                                    const unsigned char* __restrict__ cand,
                                                     const i64* __restrict__ lp_acc,
                                                     const int* __restrict__ clsmin,
                                                     const int* __restrict__ clsmax,
@@ -756,24 +819,21 @@ __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
                                                     int* __restrict__ rootlist,
                                                     int* __restrict__ nroots,
                                                     int* __restrict__ violations) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool is_root = p < P.N && S.parent[p] == p;
-  const u64 m = __ballot(is_root);
-  if (m) {                                  // wave-aggregated append (roots are few)
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(nroots, __popcll(m));
-    base = __shfl(base, leader);
-    if (is_root) rootlist[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n16 = P.N >> 4;
+  if (i < n16) {
+    const uint4 f = *reinterpret_cast<const uint4*>(cand + 16 * (size_t)i);
+    if ((f.x | f.y | f.z | f.w) != 0u) {
+      const unsigned w[4] = {f.x, f.y, f.z, f.w};
+      for (int j = 0; j < 16; j++)
+        if ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu)
+          mn_cc_finish_root(P, S, 16 * i + j, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations);
+    }
   }
-  if (p >= P.N) return;
-  compsize[p] = is_root ? S.osize[p] : 0;  // kept for the certificate: osize grows in the merge
-  if (!is_root) return;
-  if (clsmin[p] != clsmax[p]) atomicAdd(violations, 1);                // (c) one class per component
-  if (S.osize[p] <= 1) return;            // a lone pixel keeps reading its class planes
-  for (int c = 0; c < P.C; c++)
-    S.lpsum[(size_t)c * P.N + p] = (float)((double)lp_acc[(size_t)c * P.N + p] * (1.0 / MN_LP_FIX));
-  S.lpvalid[p] = 1;
+  if (i < P.N - (n16 << 4)) {
+    const int p = (n16 << 4) + i;
+    if (cand[p]) mn_cc_finish_root(P, S, p, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations);
+  }
 }
 
 // ---- certificate and log-likelihood after the merge, without another sweep ----------------------
@@ -786,9 +846,9 @@ __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
 // workgroup walks the root list; the class term is summed in 2^-32 fixed point, so the order in
 // which the roots were appended does not show in the result.
 #define MN_CC_CERT_THREADS 1024
-__global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(
-    ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ compsize,
-    const int* __restrict__ rootlist, const int* __restrict__ nroots, int nb_edges,
+__device__ __forceinline__ void mn_cc_certificate_run(
+    const ImgParams& P, const ObjState& S, const unsigned char* __restrict__ cls0,
+    const int* __restrict__ compsize, const int* __restrict__ rootlist, int n, int nb_edges,
     const double* __restrict__ partial_edges, const Counters* __restrict__ cnt,
     double* __restrict__ out, int* __restrict__ violations) {
   __shared__ double sh[2][MN_CC_CERT_THREADS];
@@ -796,7 +856,6 @@ __global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(
   __shared__ int s_bad;
   if (threadIdx.x == 0) { s_cls = 0; s_bad = 0; }
   __syncthreads();
-  const int n = *nroots;
   i64 t_cls = 0;
   int bad_cls = 0;
   for (int j = threadIdx.x; j < n; j += MN_CC_CERT_THREADS) {
@@ -821,11 +880,20 @@ __global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double cls_term = (double)(i64)s_cls * (1.0 / MN_LP_FIX);
+    const double cls_term = (double)(i64)s_cls * (1.0 / 4294967296.0);
     const double moved = (double)cnt->merged_S * (1.0 / MN_FIX_ONE);
     out[0] = cls_term + ((sh[1][0] + sh[0][0]) + moved) * (double)P.omf;
     out[1] = cls_term; out[2] = sh[0][0]; out[3] = sh[1][0];
     if (cnt->merged_E) atomicAdd(violations, cnt->merged_E);
     if (s_bad) atomicAdd(violations + 3, s_bad);
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(MN_CC_CERT_THREADS) void mn_cc_certificate(
+    ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ compsize,
+    const int* __restrict__ rootlist, const int* __restrict__ nroots, int nb_edges,
+    const double* __restrict__ partial_edges, const Counters* __restrict__ cnt,
+    double* __restrict__ out, int* __restrict__ violations) {
+  mn_cc_certificate_run(P, S, cls0, compsize, rootlist, *nroots, nb_edges, partial_edges, cnt, out, violations);
 }

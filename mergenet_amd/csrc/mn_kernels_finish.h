@@ -219,18 +219,11 @@ __device__ __forceinline__ unsigned mn_fin_word(float st) {
   return (st >= 0.0f) ? (((st == 0.0f) ? 0u : __float_as_uint(st)) + 1u) : 0u;
 }
 
-// `spec` set (components mode): the host has not seen the record count yet.  R is read from
-// spec[0]; if it exceeds spec_limit, or the separability check counted violations (spec[1][0] != 0),
-// the kernel does nothing and the host, which learns both at its one synchronisation, redoes the
-// image on the ordinary path.
-__global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
-    ImgParams P, ObjState S, RecList L, int R, int* __restrict__ maprec, int* __restrict__ lists,
-    Counters* __restrict__ cnt, long long max_steps, const int* __restrict__ spec_records,
-    const int* __restrict__ spec_violations, int spec_limit, int* __restrict__ lcount) {
-  if (spec_records) {
-    R = *spec_records;
-    if (R > spec_limit || spec_violations[0] != 0 || spec_violations[1] != 0) return;   // uniform
-  }
+// The loop itself, callable from a kernel of MN_FIN2_THREADS lanes with MN_FIN2_MAXR * 12 bytes of
+// dynamic shared memory (mn_finisher_lds below; mn_cc_tail runs it between its other stages).
+__device__ __forceinline__ void mn_fin_lds_run(
+    const ImgParams& P, const ObjState& S, const RecList& L, int R, int* __restrict__ maprec,
+    int* __restrict__ lists, Counters* __restrict__ cnt, long long max_steps, int* __restrict__ lcount) {
   // One CU runs this loop, and what bounds a step is instruction issue (16 waves share 4 SIMDs),
   // so the per-record work of the two scans is kept to a couple of instructions: the queue is an
   // array of sortable words, the keys are two u32 arrays.
@@ -451,4 +444,19 @@ __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
     cnt->merged_S = merged_S;
     cnt->merged_E = merged_E;
   }
+}
+
+// `spec` set (components mode): the host has not seen the record count yet.  R is read from
+// spec[0]; if it exceeds spec_limit, or the separability check counted violations (spec[1][0] != 0),
+// the kernel does nothing and the host, which learns both at its one synchronisation, redoes the
+// image on the ordinary path.
+__global__ __launch_bounds__(MN_FIN2_THREADS) void mn_finisher_lds(
+    ImgParams P, ObjState S, RecList L, int R, int* __restrict__ maprec, int* __restrict__ lists,
+    Counters* __restrict__ cnt, long long max_steps, const int* __restrict__ spec_records,
+    const int* __restrict__ spec_violations, int spec_limit, int* __restrict__ lcount) {
+  if (spec_records) {
+    R = *spec_records;
+    if (R > spec_limit || spec_violations[0] != 0 || spec_violations[1] != 0) return;   // uniform
+  }
+  mn_fin_lds_run(P, S, L, R, maprec, lists, cnt, max_steps, lcount);
 }
