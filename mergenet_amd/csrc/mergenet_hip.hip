@@ -537,17 +537,13 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
     if (lds > c->cc_sum_lds) {
-      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums<0>),
+      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       c->cc_sum_lds = lds;
     }
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
-    if (P.C == 9)           // the Cityscapes class count (egs/cityscape/local/segment.py:38)
-      hipLaunchKernelGGL(mn_cc_class_sums<9>, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
-                         c->lp_acc, clsmin, clsmax);
-    else
-      hipLaunchKernelGGL(mn_cc_class_sums<0>, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
-                         c->lp_acc, clsmin, clsmax);
+    hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
+                       c->lp_acc, clsmin, clsmax);
   }
   MN_HIP(hipEventRecord(c->ev[8], st));
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,

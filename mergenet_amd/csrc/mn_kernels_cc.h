@@ -536,10 +536,6 @@ __device__ __forceinline__ int mn_cc_argmax_logf(const ImgParams& P, int p) {
   return b;
 }
 
-// CT > 0: compile-time class count, ALL class planes of the lane are requested before the first is
-// used (one HBM round trip per wave instead of C: the grid is a single residency of the chip, so a
-// wave's dependent chain is the kernel's duration).  CT == 0: any class count, one plane ahead.
-template <int CT>
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc,
     int* __restrict__ clsmin, int* __restrict__ clsmax) {
@@ -580,26 +576,13 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     // the next plane's load is issued before this plane's values are used (one extra float4 of
     // registers: the kernel stays at two 1024-thread blocks per CU, which matters more here than
-    // deeper staging -- three planes in flight at 85 VGPRs measured slower)
-    float4 stage[CT > 0 ? CT : 1];
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (CT > 0) {
-#pragma unroll
-      for (int c = 0; c < CT; c++)
-        stage[c] = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)i);
-    } else {
-      nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
-    }
-#pragma unroll
-    for (int c = 0; c < (CT > 0 ? CT : P.C); c++) {
-      float4 v;
-      if (CT > 0) {
-        v = stage[c];
-      } else {
-        v = nxt;
-        if (c + 1 < P.C)
-          nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
-      }
+    // deeper staging -- three planes in flight at 85 VGPRs measured slower, and so did ALL nine
+    // in flight at 82 VGPRs with the cheaper arithmetic of round 2: 37.9 against 30.4 us)
+    float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
+    for (int c = 0; c < P.C; c++) {
+      float4 v = nxt;
+      if (c + 1 < P.C)
+        nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
       if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
       if (c == 0) {
         best = v;
