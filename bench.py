@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-general-path", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="images in flight per GPU (contexts + host threads + streams); 1 = serial")
     args = ap.parse_args()
@@ -143,7 +145,8 @@ def main():
     mergers2 = [merger, seg.Merger(H, W, C, O, device=local_rank)]
     main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
-                               merge_logprob_bias=OPTS[2], mode=args.mode)
+                               merge_logprob_bias=OPTS[2], mode=args.mode,
+                               debug_flags=2 if args.no_kernel_events else 0)
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
     ex = MaskExchange(H, W, dev) if world > 1 else None

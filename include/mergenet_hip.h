@@ -80,7 +80,8 @@ typedef struct mn_options {
                                   thousandths of the round's best gain (0 = default 100, <0 = off;
                                   parity with the reference was lost at 10, once in 65 runs at 25, never from 50 up)   */
   int debug_flags;             /* bit 0: use the generic edge pass where the fast form would run (tests
-                                  compare the two); 0 in production                                */
+                                  compare the two); bit 1: no per-kernel timestamps in components mode
+                                  (ms_cc_* stay 0; each is an event on the caller's stream)        */
   int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
                                   order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
                                   has at most exact_limit_proof initial records, else the call returns

@@ -60,6 +60,7 @@ struct mn_context {
   int* touched_list;
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready, tail_lds_ready;
+  int cc_clean;           // 1: counters and the speculative record table were cleared at the end of the last image
   HashTab T;
   // output / scratch
   int* block_count;
@@ -83,6 +84,7 @@ struct mn_context {
   unsigned* cc_bits;            // [N] positive out-edges of every pixel (mn_cc_sign)
   int* cc_roots;                // [N] component roots (mn_cc_finish)
   unsigned* cc_negcnt;          // negative edges per block of the sign sweep
+  int cc_sign_blocks;           // blocks of the last sign sweep (regions of the list, partial sums)
   u64* cc_neglist;              // one region per block of the sign sweep, able to hold every edge of the block
   size_t cc_cap_max;
   hipEvent_t ev[12];   // 0-4 phases, 6-11 components-mode kernels
@@ -193,7 +195,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->cc_bits, N));
   MN_HIP(dev_alloc(c, &c->cc_roots, N));
   MN_HIP(dev_alloc(c, &c->cc_negcnt, N / MN_CC_SIGN_THREADS + 2));
-  MN_HIP(dev_alloc(c, &c->cc_neglist, R + 2 * 1024 * (size_t)c->maxO));
+  MN_HIP(dev_alloc(c, &c->cc_neglist, R + ((size_t)c->maxW / 64 + 2) * 1024 * (size_t)c->maxO));
   MN_HIP(dev_alloc(c, &c->T.key, cap));
   MN_HIP(dev_alloc(c, &c->T.S, cap));
   MN_HIP(dev_alloc(c, &c->T.st, cap));
@@ -414,9 +416,8 @@ static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool e
   }
   fills->launch(st);
   if (components) {
+    // one event for three timestamps: elapsed(ev[0], ev[0]) = 0 for the phases this mode does not have
     MN_HIP(hipEventRecord(c->ev[0], st));
-    MN_HIP(hipEventRecord(c->ev[1], st));
-    MN_HIP(hipEventRecord(c->ev[2], st));
     return MN_OK;
   }
   hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
@@ -491,8 +492,8 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
   }
 }
 
-static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, bool wait, bool with_ball,
-                          bool with_compact) {
+static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bool wait, bool with_ball,
+                          bool with_compact, bool fork_after_sums) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256);
@@ -504,18 +505,24 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
     if (kh < 0 && P.di[k] == 0 && P.dj[k] == 1) kh = k;
     if (kv < 0 && P.dj[k] == 0 && (P.di[k] == 1 || P.di[k] == -1)) { kv = k; dv = P.di[k]; }
   }
+  const bool few_events = (c->debug_flags & 2) != 0;   // no per-kernel timestamps on the caller's stream
   // negative-edge list: one region per block of the sign sweep, able to hold every edge of the block
   u64* neg_list = c->cc_neglist;
-  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
-  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);   // per block
-  MN_HIP(hipEventRecord(c->ev[6], st));
-  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap);
-  else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
-  MN_HIP(hipEventRecord(c->ev[10], st));
   const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
+  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+  c->cc_sign_blocks = (int)sign_blocks;
+  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);   // per block
   // class range of the components: `root` and `mapbuf` are free until the output stage
   int* clsmin = c->root;
   int* clsmax = c->mapbuf;
+  // (ev[0], recorded by run_phase_a right before, is the start of the sweep: every event on the
+  // caller's stream costs a ~6 us dispatch gap)
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap);
+  else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
+  if (!few_events) MN_HIP(hipEventRecord(c->ev[10], st));
+  // (labelling the tiles inside the sign sweep -- a block = a 16 x 64 tile -- was tried: 40.6 us for
+  // the fused kernel against 27 + 15 apart; the LDS union-find and its barriers sit on every block's
+  // critical path and the tile layout reads 256-byte row segments)
   hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv,
                      c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
@@ -533,7 +540,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
   // caller's fill
   HashTab T = c->T;
   T.mask = (unsigned)(c->cc_cap - 1);
-  MN_HIP(hipEventRecord(c->ev[7], st));
+  if (!few_events) MN_HIP(hipEventRecord(c->ev[7], st));
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
     if (lds > c->cc_sum_lds) {
@@ -545,7 +552,16 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t st, boo
     hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
                        c->lp_acc, clsmin, clsmax);
   }
-  MN_HIP(hipEventRecord(c->ev[8], st));
+  if (!few_events) MN_HIP(hipEventRecord(c->ev[8], st));
+  if (fork_after_sums) {
+    // From here on the image is latency-bound work of a few workgroups (and one pixel-wide mask
+    // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
+    // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
+    // for the side stream; nothing of this image is left on the caller's stream after this point.
+    MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    st = c->side;
+  }
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
                      (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
                      c->scalars + 6, c->cc_tcount);
@@ -612,14 +628,17 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->merges = merges;
     stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
+    const bool cmode = mode == MN_MODE_COMPONENTS;     // (no separate scoring phase: ev[1], ev[2] not recorded)
+    if (!cmode) {
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
+    }
     stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
-    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_merge = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[cmode ? 0 : 2], c->ev[3]); stats->ms_merge = ms;
     (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
-    if (mode == MN_MODE_COMPONENTS) {
-      (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[10]); stats->ms_cc_edges = ms;
+    if (mode == MN_MODE_COMPONENTS && !(opts->debug_flags & 2)) {
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[10]); stats->ms_cc_edges = ms;
       (void)hipEventElapsedTime(&ms, c->ev[10], c->ev[7]); stats->ms_cc_label = ms;
       (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
       (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_cross = ms;
@@ -702,12 +721,18 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       fills.add(c->gmax, 64 * sizeof(unsigned), 0);
     }
   }
+  // A fused speculative attempt clears the same few kilobytes again at its END, on the side stream
+  // (after the statistics have been copied out): the next one starts with its sweep over the
+  // sameness planes instead of a fill kernel and the dispatch gap behind it.
+  FillList post = fills;
+  if (fused_tail && c->cc_clean) fills.j.count = 0;
+  c->cc_clean = 0;                 // (set again only when this attempt has queued its own clean-up)
 
   // ---------------- phase A ----------------
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
-    rc = run_components(c, P, st, !speculate, !speculate, !fused_tail);
+    rc = run_components(c, P, st, !speculate, !speculate, !fused_tail, fused_tail);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
@@ -781,13 +806,6 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   const bool want_cert = opts->compute_logprob != 0;
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
   if (fused_tail) {
-    // From here on the image is one workgroup's work (and one pixel-wide mask write): it moves to
-    // the context's side stream, so that the sweeps of the NEXT image (another context, the
-    // caller's stream) run beside it instead of behind it.  mn_segment_finish waits for the side
-    // stream; nothing of this image is left on the caller's stream after this point.
-    MN_HIP(hipEventRecord(c->ev_fork, st));
-    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    st = c->side;
     if (!c->tail_lds_ready) {
       MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_tail),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, MN_FIN2_MAXR * 12));
@@ -796,7 +814,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     HashTab T = c->T;
     T.mask = (unsigned)(c->cc_cap - 1);
     const long long max_steps = 64LL * (R0 > 0 ? R0 : 1) + 4096;
-    const int nbe = (int)grid_for((size_t)(P.W % 4 == 0 ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+    const int nbe = c->cc_sign_blocks;
     hipLaunchKernelGGL(mn_cc_tail, dim3(1), dim3(MN_FIN2_THREADS), MN_FIN2_MAXR * 12, st, P, S, T,
                        (const int*)c->cc_tcount, cur, c->cc_lcount, c->label, c->fin_lists, c->cnt, max_steps,
                        c->scalars, finish_limit, (const unsigned char*)c->cls0, (const int*)c->mate,
@@ -856,7 +874,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   } else if (mode == MN_MODE_COMPONENTS && rounds == 0 && R <= MN_FIN2_MAXR) {
     // no further sweep over the sameness planes: the edge sweep of the contraction left the sums
     // for the components and the finisher what the merged records moved (mn_cc_certificate)
-    const int nbe = (int)grid_for((size_t)(P.W % 4 == 0 ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+    const int nbe = c->cc_sign_blocks;
     hipLaunchKernelGGL(mn_cc_certificate, dim3(1), dim3(MN_CC_CERT_THREADS), 0, st, P, S,
                        (const unsigned char*)c->cls0, (const int*)c->mate, (const int*)c->cc_roots,
                        (const int*)(c->scalars + 8), nbe, (const double*)c->partial,
@@ -885,6 +903,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   c->last_valid = 1;
 
   MN_HIP(hipMemcpyAsync(c->h_statblk, c->statblk, MN_STAT_BYTES, hipMemcpyDeviceToHost, st));
+  if (fused_tail) {                // (st is the side stream here)
+    post.launch(st);
+    c->cc_clean = 1;
+  }
   if (defer && speculate) {
     MN_HIP(hipEventRecord(c->ev_done, st));
     c->pend.mode = mode; c->pend.rounds = rounds; c->pend.finish_limit = finish_limit; c->pend.N = N;
@@ -1129,6 +1151,7 @@ extern "C" int mn_rle_points_device(mn_context* c, const int* d_mask, int height
   MN_HIP(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = height * width;
+  c->cc_clean = 0;                 // (writes the scalar block)
   const int nblk = (int)grid_for(N, MN_RLE_ITEMS);
   hipLaunchKernelGGL(mn_rle_count, dim3(nblk), dim3(256), 0, st, d_mask, height, width, c->block_count);
   hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->block_count, c->scalars + 5);
