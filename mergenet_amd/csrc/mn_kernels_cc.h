@@ -485,7 +485,12 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
 // table (root -> C+1 fixed-point sums); the block then issues ONE global atomic per root and class:
 // a 1.6 M-pixel background is a hot word for every wave of the image, and one word takes only ~88
 // atomics/us.  64-bit fixed-point sums (2^-32) are order-independent.
+#ifndef MN_CC_SUM_THREADS
 #define MN_CC_SUM_THREADS 1024
+#endif
+#ifndef MN_CC_SUM_AHEAD
+#define MN_CC_SUM_AHEAD 1   /* planes in flight ahead of the one in use: 1 at 1024 threads measured best (37.3 us by events; 2: 41.4, 3: 42.4; 512 threads: 43.7 / 40.8; 256: 47.6) -- occupancy matters more */
+#endif
 #define MN_CC_SUM_SLOTS 64
 __device__ __forceinline__ int mn_lds_root_slot(int* s_root, int root) {
   unsigned h = ((unsigned)root * 2654435761u) >> 26;             // 6 bits
@@ -578,11 +583,21 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     // registers: the kernel stays at two 1024-thread blocks per CU, which matters more here than
     // deeper staging -- three planes in flight at 85 VGPRs measured slower, and so did ALL nine
     // in flight at 82 VGPRs with the cheaper arithmetic of round 2: 37.9 against 30.4 us)
-    float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
-    for (int c = 0; c < P.C; c++) {
-      float4 v = nxt;
-      if (c + 1 < P.C)
-        nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
+    // MN_CC_SUM_AHEAD planes of the lane are in flight: a wave's chain of dependent HBM round trips
+    // is what the kernel's duration is made of (the grid is one residency of the chip)
+    float4 ring[MN_CC_SUM_AHEAD];
+#pragma unroll
+    for (int a = 0; a < MN_CC_SUM_AHEAD; a++)
+      ring[a] = a < P.C ? *reinterpret_cast<const float4*>(P.cls + (size_t)a * P.N + 4 * (size_t)i)
+                        : make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+    for (int c0 = 0; c0 < P.C; c0 += MN_CC_SUM_AHEAD) {
+#pragma unroll
+    for (int a = 0; a < MN_CC_SUM_AHEAD; a++) {
+      const int c = c0 + a;
+      if (c >= P.C) break;
+      float4 v = ring[a];
+      if (c + MN_CC_SUM_AHEAD < P.C)
+        ring[a] = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + MN_CC_SUM_AHEAD) * P.N + 4 * (size_t)i);
       if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
       if (c == 0) {
         best = v;
@@ -602,6 +617,7 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
         mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, (i64)__float2int_rn(logf(v.z) * (float)MN_LP_FIX));
         mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, (i64)__float2int_rn(logf(v.w) * (float)MN_LP_FIX));
       }
+    }
     }
     // a lower class within 2^-18 of the maximum (logs of magnitude < 16 are 2^-20 apart at most, and
     // the GPU's logf is within an ulp of libm's): settle it the reference's way

@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmergenet_hip.so")
+LIB_PATH = os.environ.get("MN_LIB") or os.path.join(_HERE, "libmergenet_hip.so")   # MN_LIB: a variant build (tuning only)
 
 MN_VARIANT_CSEGMENT = 0
 MN_VARIANT_PYSEGMENTER = 1
