@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
+    ap.add_argument("--wire", default="runs", choices=["runs", "int16"],
+                    help="wire format of the mask exchange for N > 1 (run-length change points | int16 map)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="images in flight per GPU (contexts + host threads + streams); 1 = serial")
     args = ap.parse_args()
@@ -149,7 +151,7 @@ def main():
                                debug_flags=2 if args.no_kernel_events else 0)
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
-    ex = MaskExchange(H, W, dev) if world > 1 else None
+    ex = MaskExchange(H, W, dev, fmt=args.wire, merger=merger) if world > 1 else None
 
     from collections import deque
 
@@ -214,10 +216,13 @@ def main():
     if args.warmup:
         run_steps(0, args.warmup, main_pool)
     fence()
+    if ex is not None:
+        ex.wait_ms = 0.0
     t0 = time.perf_counter()
     (mask, table, st, gathered), acc, modes = run_steps(args.warmup, args.steps, main_pool)
     fence()
     elapsed = time.perf_counter() - t0
+    exchange_wait_ms = ex.wait_ms if ex is not None else 0.0
 
     # the same steps with PIPELINED_DEPTH images in flight (one GPU; outside the contract line)
     pipelined = None
@@ -346,9 +351,16 @@ def main():
                                        "stream: kernels of different images do not overlap)",
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
-                       "exchange": ("one all_gather per step of int16 masks + class tables over RCCL, "
-                                    "overlapped with the next step's merge; delivered data checked: %s"
-                                    % exchange_ok) if world > 1 else "none (single GPU)"},
+                       "exchange": ("one all_gather per step of the masks (%s wire) + class tables + "
+                                    "log-likelihoods, overlapped with the next step's merge; delivered "
+                                    "data checked: %s" % (args.wire, exchange_ok)) if world > 1
+                       else "none (single GPU)"},
+            "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
+                            "backend": (ex.backend if ex is not None else "none"),
+                            "wire_format": (args.wire if world > 1 else None),
+                            "wire_bytes_per_rank_per_step": (ex.bytes_per_rank if ex is not None else 0),
+                            "exchange_wait_ms_per_step": round(exchange_wait_ms / max(1, args.steps), 5),
+                            "delivered_data_checked": exchange_ok},
             "roofline": roofline,
             "passes": passes,
             "phases_ms": {"score": round(avg["ms_class_pass"] + avg["ms_edge_pass"], 4),

@@ -60,6 +60,7 @@ struct mn_context {
   int* touched_list;
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready, tail_lds_ready;
+  int* wire_counts;       // block counts + total of mn_pack_runs_device (apart from the image's own scratch)
   int cc_clean;           // 1: counters and the speculative record table were cleared at the end of the last image
   HashTab T;
   // output / scratch
@@ -201,6 +202,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->T.st, cap));
   MN_HIP(dev_alloc(c, &c->T.touched, cap));
   MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
+  MN_HIP(dev_alloc(c, &c->wire_counts, N / MN_RLE_ITEMS + 4));
   MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
   {
     const size_t o_sc = (sizeof(Counters) + 15) & ~(size_t)15, o_lp = o_sc + MN_NSCALARS * sizeof(int);
@@ -257,7 +259,7 @@ extern "C" void mn_destroy(mn_context* c) {
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
                  c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist, c->T.key,
-                 c->T.S, c->T.st, c->T.touched, c->block_count, c->partial, c->statblk,
+                 c->T.S, c->T.st, c->T.touched, c->block_count, c->wire_counts, c->partial, c->statblk,
                  c->bg_key, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
@@ -1224,3 +1226,126 @@ extern "C" int mn_pack_wire_device(const int* d_mask, const int* d_object_class,
   return MN_OK;
 }
 
+
+extern "C" size_t mn_runs_wire_words(int capacity, int max_instances) {
+  if (capacity <= 0 || max_instances <= 0) return 0;
+  return 4 + (size_t)capacity + (size_t)(capacity + 1) / 2 + (size_t)(max_instances + 3) / 4;
+}
+
+extern "C" int mn_pack_runs_device(mn_context* c, const int* d_mask, const int* d_object_class,
+                                   int num_instances, double total_logprob, int n_pixels, int capacity,
+                                   int max_instances, int* d_wire, void* stream) {
+  if (!c || !d_mask || !d_object_class || !d_wire || n_pixels <= 0 || (size_t)n_pixels > c->N ||
+      capacity <= 0 || max_instances <= 0 || num_instances < 0 || num_instances > max_instances ||
+      num_instances > 32767) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nblk = (int)grid_for(n_pixels, MN_RLE_ITEMS);
+  int* total = c->wire_counts + nblk;
+  hipLaunchKernelGGL(mn_runs_count, dim3(nblk), dim3(256), 0, st, d_mask, n_pixels, c->wire_counts);
+  hipLaunchKernelGGL(mn_rank_scan, dim3(1), dim3(1024), 0, st, nblk, c->wire_counts, total);
+  hipLaunchKernelGGL(mn_runs_scatter, dim3(nblk), dim3(256), 0, st, d_mask, n_pixels,
+                     (const int*)c->wire_counts, (const int*)total, capacity, max_instances, num_instances,
+                     total_logprob, d_object_class, d_wire);
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+extern "C" int mn_unpack_runs_device(const int* d_wire, int n_pixels, int capacity, int max_instances,
+                                     int* d_mask, int* d_table, void* stream) {
+  if (!d_wire || !d_mask || n_pixels <= 0 || capacity <= 0 || max_instances <= 0) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  const size_t threads = (size_t)n_pixels > (size_t)max_instances ? (size_t)n_pixels : (size_t)max_instances;
+  hipLaunchKernelGGL(mn_runs_unpack, dim3(grid_for(threads, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_wire, n_pixels, capacity, max_instances, d_mask, d_table);
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+// ---- COCO RLE strings on the host (native twin of mergenet_amd/rle.py::from_change_points) ------
+static inline void rle_put(unsigned char* out, long long cap, long long& w, long long x) {
+  bool more = true;
+  while (more) {
+    int ch = (int)(x & 0x1F);
+    x >>= 5;                                  // arithmetic shift: keeps the sign
+    more = (ch & 0x10) ? (x != -1) : (x != 0);
+    if (more) ch |= 0x20;
+    if (w < cap) out[w] = (unsigned char)(ch + 48);
+    w++;
+  }
+}
+
+extern "C" long long mn_rle_encode_host(const int* points, int capacity, int n, int height, int width,
+                                        int num_instances, unsigned char* out, long long out_capacity,
+                                        long long* offsets, int* areas) {
+  if (!points || n < 0 || capacity < n || height <= 0 || width <= 0 || num_instances < 0 || !offsets ||
+      (!out && out_capacity > 0))
+    return MN_ERR_ARGUMENT;
+  const int* pos = points;
+  const int* prev = points + capacity;
+  const int* cur = points + 2 * (size_t)capacity;
+  const long long N = (long long)height * width;
+  const int K = num_instances;
+  // a change point (j, a, b) ends a run of label a and starts a run of label b at j; positions are
+  // ascending, so the starts (and ends) of one label are ascending too: two counting passes
+  int* first = static_cast<int*>(calloc((size_t)2 * (K + 2), sizeof(int)));
+  int* buf = static_cast<int*>(malloc(sizeof(int) * (size_t)(2 * (n > 0 ? n : 1))));
+  if (!first || !buf) { free(first); free(buf); return MN_ERR_INTERNAL; }
+  int* sfirst = first;
+  int* efirst = first + K + 2;
+  for (int i = 0; i < n; i++) {
+    if (cur[i] >= 1 && cur[i] <= K) sfirst[cur[i] + 1]++;
+    if (prev[i] >= 1 && prev[i] <= K) efirst[prev[i] + 1]++;
+  }
+  for (int k = 1; k <= K + 1; k++) { sfirst[k] += sfirst[k - 1]; efirst[k] += efirst[k - 1]; }
+  int* starts = buf;
+  int* ends = buf + n;
+  {
+    int* sw = static_cast<int*>(malloc(sizeof(int) * (size_t)(2 * (K + 2))));
+    if (!sw) { free(first); free(buf); return MN_ERR_INTERNAL; }
+    int* ew = sw + K + 2;
+    memcpy(sw, sfirst, sizeof(int) * (size_t)(K + 2));
+    memcpy(ew, efirst, sizeof(int) * (size_t)(K + 2));
+    for (int i = 0; i < n; i++) {
+      if (cur[i] >= 1 && cur[i] <= K) starts[sw[cur[i]]++] = pos[i];
+      if (prev[i] >= 1 && prev[i] <= K) ends[ew[prev[i]]++] = pos[i];
+    }
+    free(sw);
+  }
+  long long w = 0;
+  for (int k = 1; k <= K; k++) {
+    offsets[k - 1] = w;
+    const int s0 = sfirst[k], s1 = sfirst[k + 1], e0 = efirst[k], e1 = efirst[k + 1];
+    long long last = 0, c2 = 0, c1 = 0;      // the counts one and two places back
+    long long area = 0;
+    int emitted = 0;
+    auto emit = [&](long long c) {
+      long long x = c;
+      if (emitted > 2) x -= c2;
+      rle_put(out, out_capacity, w, x);
+      c2 = c1; c1 = c;
+      emitted++;
+    };
+    for (int i = s0; i < s1; i++) {
+      const long long a = starts[i];
+      const long long b = (e0 + (i - s0) < e1) ? ends[e0 + (i - s0)] : N;   // the last run may reach the end
+      emit(a - last);
+      emit(b - a);
+      area += b - a;
+      last = b;
+    }
+    if (last < N || emitted == 0) emit(N - last);
+    if (areas) areas[k - 1] = (int)area;
+  }
+  offsets[K] = w;
+  free(first);
+  free(buf);
+  return w;
+}

@@ -48,42 +48,115 @@ def gather_masks(mask, class_table, num_instances: int):
     return torch.stack(masks), tabs[:, 1:], tabs[:, 0].clone()
 
 
+def runs_capacity(n_pixels: int) -> int:
+    """Change points the run-length wire holds: n_pixels / 32 (10.6x below the int16 map)."""
+    return max(64, n_pixels // 32)
+
+
+def pack_runs_cpu(mask, class_table, num_instances: int, total_logprob: float, capacity: int,
+                  max_instances: int = MAX_INSTANCES):
+    """CPU twin of ``mn_pack_runs_device`` (torch tensors; the gloo tests and the checker of the
+    device kernels): int32 wire of ``4 + cap + (cap+1)//2 + (max_instances+3)//4`` words."""
+    import torch
+    flat = mask.reshape(-1).to(torch.int32)
+    prev = torch.cat([torch.zeros(1, dtype=torch.int32), flat[:-1]])
+    pos = torch.nonzero(flat != prev).reshape(-1).to(torch.int32)
+    words = 4 + capacity + (capacity + 1) // 2 + (max_instances + 3) // 4
+    wire = torch.zeros(words, dtype=torch.int32)
+    n = int(pos.numel())
+    wire[0] = n if n <= capacity else -1
+    wire[1] = int(num_instances)
+    wire[2:4] = torch.tensor([total_logprob], dtype=torch.float64).view(torch.int32)
+    m = min(n, capacity)
+    wire[4:4 + m] = pos[:m]
+    labels = wire[4 + capacity: 4 + capacity + (capacity + 1) // 2].view(torch.int16)
+    labels[:m] = flat[pos[:m].long()].to(torch.int16)
+    classes = wire[4 + capacity + (capacity + 1) // 2:].view(torch.int8)
+    classes[:max_instances] = -1
+    classes[:num_instances] = class_table[:num_instances].to(torch.int8)
+    return wire
+
+
+def unpack_runs_cpu(wire, height: int, width: int, capacity: int, max_instances: int = MAX_INSTANCES):
+    """CPU twin of ``mn_unpack_runs_device``: (mask int32 [H,W], classes int32 [max_instances], K, loglik)."""
+    import torch
+    n = int(wire[0])
+    if n < 0:
+        raise ValueError("run-length wire overflowed its capacity on the sending rank")
+    pos = wire[4:4 + n].long()
+    labels = wire[4 + capacity: 4 + capacity + (capacity + 1) // 2].view(torch.int16)[:n].to(torch.int32)
+    N = height * width
+    idx = torch.searchsorted(pos, torch.arange(N), right=True)
+    full = torch.cat([torch.zeros(1, dtype=torch.int32), labels])
+    mask = full[idx].reshape(height, width)
+    classes = wire[4 + capacity + (capacity + 1) // 2:].view(torch.int8)[:max_instances].to(torch.int32)
+    loglik = float(wire[2:4].clone().view(torch.float64)[0])
+    return mask, classes, int(wire[1]), loglik
+
+
 class MaskExchange:
     """Asynchronous, double-buffered all-gather of one image per rank and step.
 
-    The merger needs 0.4 ms per 1024x2048 image; an int32 mask is 8 MiB, so a blocking exchange of
+    The merger needs ~0.2 ms per 1024x2048 image; an int32 mask is 8 MiB, so a blocking exchange of
     8 of them over xGMI would cost more than the merge.  Two things keep the links off the critical
-    path: the wire format is one int16 buffer per image -- ``[H*W labels][K][MAX_INSTANCES classes,
-    -1 padded][float64 log-likelihood as 4 words]`` (labels <= 4096, classes < 128), half the
-    bytes and ONE collective instead of two
-    -- and the collective of step i runs on the backend's own stream while the kernels of step
-    i+1 run on the compute stream (``async_op``); a buffer is reused only after its collective
-    has been waited for.
+    path: the wire format and the overlap.
 
-        ex = MaskExchange(H, W, device)
+    * ``fmt="runs"`` (default): the row-major label change points of the mask -- the masks are
+      piecewise constant -- with K, the class table and the log-likelihood in the same buffer:
+      397 KB per 1024x2048 image (``mn_pack_runs_device``; capacity n_pixels / 32 change points, a
+      mask with more reports -1 and ``result`` raises).  ``fmt="int16"``: one int16 per pixel
+      (4.2 MB; ``mn_pack_wire_device``), for masks that do not compress and as the checked
+      reference of the tests.  Either way ONE collective per step.
+    * the collective of step i runs on the backend's own stream while the kernels of step i+1 run
+      on the compute stream (``async_op``); a buffer is reused only after its collective has been
+      waited for.  ``wait_ms`` sums the host time spent waiting for collectives.
+
+        ex = MaskExchange(H, W, device, merger=merger)
         slot = ex.submit(mask, class_table, K)      # returns at once
         ...                                          # next image
-        masks, tables, counts = ex.result(slot)      # int16 [world,H,W], int16 [world,4096], [world]
+        masks, tables, counts = ex.result(slot)      # [world,H,W], [world,4096], [world]
         logliks = ex.logprobs(slot)                  # float64 [world]
         ex.drain()
     """
 
-    def __init__(self, height: int, width: int, device, depth: int = 2):
+    def __init__(self, height: int, width: int, device, depth: int = 2, fmt: str = "runs", merger=None):
         import torch
         import torch.distributed as dist
+        if fmt not in ("runs", "int16"):
+            raise ValueError("fmt is 'runs' or 'int16'")
         self.torch, self.dist = torch, dist
         self.H, self.W, self.n = height, width, height * width
-        self.words = self.n + 1 + MAX_INSTANCES + 4
+        self.fmt, self.merger = fmt, merger
+        self.cap = runs_capacity(self.n)
+        if fmt == "runs":
+            self.words = 4 + self.cap + (self.cap + 1) // 2 + (MAX_INSTANCES + 3) // 4
+            dtype = torch.int32
+        else:
+            self.words = self.n + 1 + MAX_INSTANCES + 4
+            dtype = torch.int16
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.backend = dist.get_backend() if self.world > 1 else "none"
         self.depth = depth
-        self.send = [torch.empty(self.words, dtype=torch.int16, device=device) for _ in range(depth)]
-        self.recv = [torch.empty(self.world * self.words, dtype=torch.int16, device=device)
+        self.send = [torch.empty(self.words, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [torch.empty(self.world * self.words, dtype=dtype, device=device)
                      for _ in range(depth)]
         self.work = [None] * depth
         self.count = 0
+        self.wait_ms = 0.0
+        self.bytes_per_rank = self.words * (4 if fmt == "runs" else 2)
 
     def _pack(self, mask, class_table, num_instances, wire, total_logprob):
         torch = self.torch
+        if self.fmt == "runs":
+            if mask.is_cuda:
+                from . import segmenter
+                if self.merger is None:
+                    raise ValueError("MaskExchange(fmt='runs') on the GPU needs merger= (scratch of the pack kernels)")
+                segmenter.pack_runs(self.merger, mask, class_table, num_instances, wire, self.cap,
+                                    MAX_INSTANCES, total_logprob)
+            else:
+                wire.copy_(pack_runs_cpu(mask, class_table, num_instances, total_logprob, self.cap))
+            return
         if mask.is_cuda:                      # HIP kernel of the library, on the current stream
             from . import segmenter
             segmenter.pack_wire(mask, class_table, num_instances, wire, MAX_INSTANCES, total_logprob)
@@ -113,22 +186,41 @@ class MaskExchange:
 
     def wait(self, slot: int) -> None:
         if self.work[slot] is not None:
+            import time
+            t = time.perf_counter()
             self.work[slot].wait()
+            self.wait_ms += (time.perf_counter() - t) * 1e3
             self.work[slot] = None
 
     def result(self, slot: int):
+        """(masks [world,H,W], class tables [world,MAX_INSTANCES] padded with -1, counts [world])."""
         self.wait(slot)
+        torch = self.torch
         r = self.recv[slot].view(self.world, self.words)
-        return (r[:, : self.n].view(self.world, self.H, self.W),
-                r[:, self.n + 1: self.n + 1 + MAX_INSTANCES], r[:, self.n])
+        if self.fmt == "int16":
+            return (r[:, : self.n].view(self.world, self.H, self.W),
+                    r[:, self.n + 1: self.n + 1 + MAX_INSTANCES], r[:, self.n])
+        if bool((r[:, 0] < 0).any()):
+            raise ValueError("a rank's mask has more than %d label changes: use fmt='int16'" % self.cap)
+        masks, tabs = [], []
+        for w in range(self.world):
+            if r.is_cuda:
+                from . import segmenter
+                m, t = segmenter.unpack_runs(r[w], self.H, self.W, self.cap, MAX_INSTANCES)
+            else:
+                m, t, _, _ = unpack_runs_cpu(r[w], self.H, self.W, self.cap)
+            masks.append(m)
+            tabs.append(t)
+        return torch.stack(masks), torch.stack(tabs), r[:, 1].clone()
 
     def logprobs(self, slot: int):
         """Total log-likelihood of every rank's image (float64 [world])."""
         self.wait(slot)
         r = self.recv[slot].view(self.world, self.words)
+        if self.fmt == "runs":
+            return r[:, 2:4].reshape(-1).clone().view(self.torch.float64)
         return r[:, self.n + 1 + MAX_INSTANCES:].reshape(-1).clone().view(self.torch.float64)
 
     def drain(self) -> None:
         for slot in range(self.depth):
             self.wait(slot)
-

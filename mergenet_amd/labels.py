@@ -61,3 +61,21 @@ def masks_equivalent(mask_a, classes_a, mask_b, classes_b) -> bool:
         if classes_a[la - 1] != classes_b[lb - 1]:
             return False
     return True
+
+
+def agreement(mask_a, mask_b) -> int:
+    """Pixels on which two label maps agree under the best one-to-one matching of their labels by
+    overlap (greedy on the contingency table, largest overlap first)."""
+    a = np.asarray(mask_a).astype(np.int64).reshape(-1)
+    b = np.asarray(mask_b).astype(np.int64).reshape(-1)
+    cont = np.zeros((int(a.max()) + 1, int(b.max()) + 1), np.int64)
+    np.add.at(cont, (a, b), 1)
+    agree = 0
+    for _ in range(min(cont.shape)):
+        i, j = np.unravel_index(int(np.argmax(cont)), cont.shape)
+        if cont[i, j] <= 0:
+            break
+        agree += int(cont[i, j])
+        cont[i, :] = -1
+        cont[:, j] = -1
+    return agree

@@ -73,8 +73,8 @@ _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
            "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_segment_host", "c_run_segmentation",
-           "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_sameness_targets_device", "mn_instance_scores_device",
-           "mn_pack_wire_device",
+           "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
+           "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -136,6 +136,10 @@ def load_library() -> ctypes.CDLL:
     lib.mn_rle_points_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int, _i32p, ctypes.c_void_p]
     lib.mn_rle_points_device.restype = ctypes.c_int
+    lib.mn_rle_encode_host.argtypes = [_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong,
+                                       ctypes.POINTER(ctypes.c_longlong), _i32p]
+    lib.mn_rle_encode_host.restype = ctypes.c_longlong
     lib.mn_sameness_targets_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.c_int, _i32p, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p]
@@ -145,6 +149,15 @@ def load_library() -> ctypes.CDLL:
     lib.mn_pack_wire_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.mn_pack_wire_device.restype = ctypes.c_int
+    lib.mn_runs_wire_words.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mn_runs_wire_words.restype = ctypes.c_size_t
+    lib.mn_pack_runs_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_pack_runs_device.restype = ctypes.c_int
+    lib.mn_unpack_runs_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_unpack_runs_device.restype = ctypes.c_int
     lib.mn_last_status.restype = ctypes.c_int
     lib.mn_status_string.argtypes = [ctypes.c_int]
     lib.mn_status_string.restype = ctypes.c_char_p
@@ -473,33 +486,58 @@ class Merger:
         return out
 
 
-    def encode_rle(self, mask, num_instances: int):
+    def encode_rle(self, mask, num_instances: int, drop_zero_area: bool = False):
         """COCO run-length encoding of every instance of an int32 [H,W] mask on this GPU.
 
         Equivalent of ``[maskUtils.encode(np.asfortranarray(mask == i)) for i in 1..K]``
-        (egs/cityscape/local/segment.py:165-186) from ONE device pass over the mask; returns a list
-        of ``{"size": [H, W], "counts": bytes}`` with pycocotools' compressed counts string.
+        (egs/cityscape/local/segment.py:165-186) from ONE device pass over the mask (the run
+        boundaries of all instances at once) and one native host pass that groups them and writes
+        pycocotools' compressed counts strings.  Returns a list of ``{"size": [H, W], "counts": bytes,
+        "area": pixels, "label": k}``, one per instance in label order; ``drop_zero_area`` leaves out
+        instances without pixels (e.g. lost in the nearest-neighbour resize), as
+        ``egs/cityscape/local/evaluate.py:52-54`` does before COCOeval.
         """
-        from . import rle
         torch = self.torch
         if not (mask.is_cuda and mask.dtype == torch.int32 and mask.is_contiguous() and mask.dim() == 2):
             raise ValueError("expected a contiguous int32 [H,W] tensor on the GPU")
         H, W = mask.shape
-        cap = max(1024, H * W // 4)
+        cap = getattr(self, "_rle_cap", max(1024, H * W // 16))
         while True:
-            pts = torch.empty((3, cap), dtype=torch.int32, device=mask.device)
+            if getattr(self, "_rle_pts", None) is None or self._rle_pts.shape[1] != cap:
+                self._rle_pts = torch.empty((3, cap), dtype=torch.int32, device=mask.device)
+                self._rle_host = torch.empty((3, cap), dtype=torch.int32).pin_memory()
+                self._rle_cap = cap
             n = ctypes.c_int(0)
             stream = torch.cuda.current_stream(mask.device).cuda_stream
-            rc = self.lib.mn_rle_points_device(self.handle, mask.data_ptr(), H, W, pts.data_ptr(), cap,
-                                               ctypes.byref(n), ctypes.c_void_p(stream))
+            rc = self.lib.mn_rle_points_device(self.handle, mask.data_ptr(), H, W, self._rle_pts.data_ptr(),
+                                               cap, ctypes.byref(n), ctypes.c_void_p(stream))
             if rc == -4 and n.value > cap:
                 cap = n.value
                 continue
             if rc != 0:
                 raise MergeNetError(rc)
             break
-        p = pts[:, : n.value].cpu().numpy()
-        return rle.from_change_points(p[0], p[1], p[2], H, W, num_instances)
+        nn = n.value
+        for r in range(3):                                    # only the used part of each row travels
+            self._rle_host[r, :nn].copy_(self._rle_pts[r, :nn], non_blocking=True)
+        torch.cuda.current_stream(mask.device).synchronize()
+        K = int(num_instances)
+        offsets = (ctypes.c_longlong * (K + 1))()
+        areas = (ctypes.c_int * max(1, K))()
+        out_cap = 8 * nn + 16 * K + 64                        # a count takes at most 7 bytes
+        out = ctypes.create_string_buffer(out_cap)
+        need = self.lib.mn_rle_encode_host(ctypes.cast(self._rle_host.data_ptr(), _i32p), cap, nn, H, W, K,
+                                           ctypes.cast(out, ctypes.c_void_p), out_cap, offsets, areas)
+        if need < 0 or need > out_cap:
+            raise MergeNetError(int(need) if need < 0 else -20)
+        raw = out.raw
+        res = []
+        for k in range(1, K + 1):
+            if drop_zero_area and areas[k - 1] == 0:
+                continue
+            res.append({"size": [H, W], "counts": raw[offsets[k - 1]:offsets[k]], "area": int(areas[k - 1]),
+                        "label": k})
+        return res
 
 
     def sameness_targets(self, mask, offsets):
@@ -658,3 +696,41 @@ def pack_wire(mask, class_table, num_instances: int, wire, max_instances: int,
     if rc != 0:
         raise MergeNetError(rc)
 
+
+
+def runs_wire_words(capacity: int, max_instances: int) -> int:
+    """int32 words of the run-length wire buffer (``mn_runs_wire_words``)."""
+    return 4 + capacity + (capacity + 1) // 2 + (max_instances + 3) // 4
+
+
+def pack_runs(merger, mask, class_table, num_instances: int, wire, capacity: int, max_instances: int,
+              total_logprob: float = float("nan")) -> None:
+    """Device tensors: int32 mask [H,W] + class table -> int32 run-length wire buffer
+    (``mn_pack_runs_device``: row-major label change points; layout in include/mergenet_hip.h).
+    Runs on the current torch stream; no host synchronisation."""
+    import torch
+    n = mask.numel()
+    if (mask.dtype != torch.int32 or class_table.dtype != torch.int32 or wire.dtype != torch.int32
+            or not mask.is_contiguous() or wire.numel() < runs_wire_words(capacity, max_instances)
+            or class_table.numel() < num_instances):
+        raise AssertionError("pack_runs: int32 mask/table, int32 wire of runs_wire_words(capacity, max_instances)")
+    stream = torch.cuda.current_stream(mask.device).cuda_stream
+    rc = merger.lib.mn_pack_runs_device(merger.handle, mask.data_ptr(), class_table.data_ptr(),
+                                        int(num_instances), float(total_logprob), n, int(capacity),
+                                        int(max_instances), wire.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise MergeNetError(rc)
+
+
+def unpack_runs(wire, height: int, width: int, capacity: int, max_instances: int):
+    """Run-length wire buffer (device, int32) -> (mask int32 [H,W], class table int32 [max_instances])."""
+    import torch
+    lib = load_library()
+    mask = torch.empty((height, width), dtype=torch.int32, device=wire.device)
+    table = torch.empty((max_instances,), dtype=torch.int32, device=wire.device)
+    stream = torch.cuda.current_stream(wire.device).cuda_stream
+    rc = lib.mn_unpack_runs_device(wire.data_ptr(), height * width, int(capacity), int(max_instances),
+                                   mask.data_ptr(), table.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise MergeNetError(rc)
+    return mask, table

@@ -64,49 +64,87 @@ def test_shard_indices_cover_every_image_once():
         mnd.shard_indices(4, 4, 4)
 
 
-def _exchange_worker(rank, world, port, out):
+def _test_mask(H, W, rank, step):
+    """A piecewise-constant label map with a few rectangles (what a final instance mask looks like)."""
+    m = torch.zeros((H, W), dtype=torch.int32)
+    m[1:3, 1:4] = 1 + (rank + step) % 5
+    m[2:H, W - 3:] = 2 + (rank + 2 * step) % 4
+    m[H - 1, 0] = 1
+    return m
+
+
+def _exchange_worker(rank, world, port, out, fmt):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     H, W = 5, 7
-    ex = mnd.MaskExchange(H, W, torch.device("cpu"), depth=2)
-    ok = True
+    ex = mnd.MaskExchange(H, W, torch.device("cpu"), depth=2, fmt=fmt)
+    ok = ex.world == world and ex.backend == "gloo"
     slots = []
     # more steps than buffers: slot reuse must wait for the earlier collective
     for step in range(5):
-        mask = torch.full((H, W), (rank + step) % 7, dtype=torch.int32)
+        mask = _test_mask(H, W, rank, step)
         k = 1 + (rank + step) % 3
         table = torch.full((H * W,), -1, dtype=torch.int32)
         table[:k] = torch.arange(k, dtype=torch.int32) + 3 * rank + step
         slots.append(ex.submit(mask, table, k, -1000.5 * (rank + 1) - step))
         masks, tabs, counts = ex.result(slots[-1])
         ok &= ex.logprobs(slots[-1]).tolist() == [-1000.5 * (r + 1) - step for r in range(world)]
-        ok &= masks.dtype == torch.int16 and masks.shape == (world, H, W)
+        ok &= masks.dtype == (torch.int32 if fmt == "runs" else torch.int16) and masks.shape == (world, H, W)
         ok &= tabs.shape == (world, mnd.MAX_INSTANCES)
         for r in range(world):
             kr = 1 + (r + step) % 3
-            ok &= bool((masks[r] == (r + step) % 7).all())
+            ok &= bool((masks[r].to(torch.int32) == _test_mask(H, W, r, step)).all())
             ok &= int(counts[r]) == kr
             ok &= tabs[r, :kr].tolist() == [i + 3 * r + step for i in range(kr)]
             ok &= bool((tabs[r, kr:] == -1).all())
     ex.drain()
     ok &= slots == [0, 1, 0, 1, 0]
-    out[rank] = bool(ok)
+    ok &= ex.wait_ms >= 0.0
+    out[rank] = (bool(ok), ex.bytes_per_rank)
     dist.destroy_process_group()
 
 
-def test_mask_exchange_async_world2_gloo():
-    """The double-buffered int16 exchange bench.py uses for N > 1 (CPU tensors, gloo)."""
+@pytest.mark.parametrize("fmt", ["runs", "int16"])
+def test_mask_exchange_async_world2_gloo(fmt):
+    """The double-buffered exchange bench.py uses for N > 1 (CPU tensors, gloo): the run-length wire
+    (default) and the int16 map it replaces deliver the same masks, tables, counts, log-likelihoods."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_exchange_worker, args=(world, port, out), nprocs=world, join=True)
-    assert dict(out) == {0: True, 1: True}
+    mp.spawn(_exchange_worker, args=(world, port, out, fmt), nprocs=world, join=True)
+    assert {k: v[0] for k, v in dict(out).items()} == {0: True, 1: True}
+
+
+def test_run_length_wire_round_trip_and_size():
+    """pack_runs_cpu / unpack_runs_cpu (the CPU twins of mn_pack_runs_device / mn_unpack_runs_device):
+    random piecewise-constant masks come back exactly; a mask with too many changes says so; at
+    1024x2048 the wire is >= 10x smaller than the int16 map."""
+    g = torch.Generator().manual_seed(5)
+    for H, W in [(1, 1), (3, 5), (16, 64), (33, 70)]:
+        cap = H * W                      # (every mask fits; the production capacity is n_pixels / 32)
+        coarse = torch.randint(0, 6, ((H + 7) // 8, (W + 7) // 8), generator=g, dtype=torch.int32)
+        mask = coarse.repeat_interleave(8, 0).repeat_interleave(8, 1)[:H, :W].contiguous()
+        k = int(mask.max())
+        table = torch.arange(1, k + 1, dtype=torch.int32)
+        wire = mnd.pack_runs_cpu(mask, table, k, -12.5, cap)
+        m2, cls, k2, ll = mnd.unpack_runs_cpu(wire, H, W, cap)
+        assert torch.equal(m2, mask) and k2 == k and ll == -12.5
+        assert cls[:k].tolist() == table.tolist() and bool((cls[k:] == -1).all())
+    noisy = torch.randint(0, 9, (16, 64), generator=g, dtype=torch.int32)      # ~900 changes > capacity 64
+    wire = mnd.pack_runs_cpu(noisy, torch.arange(1, 9, dtype=torch.int32), 8, 0.0, mnd.runs_capacity(16 * 64))
+    assert int(wire[0]) == -1
+    with pytest.raises(ValueError):
+        mnd.unpack_runs_cpu(wire, 16, 64, mnd.runs_capacity(16 * 64))
+    n = 1024 * 2048
+    runs = mnd.MaskExchange(1024, 2048, torch.device("cpu"), fmt="runs").bytes_per_rank
+    i16 = mnd.MaskExchange(1024, 2048, torch.device("cpu"), fmt="int16").bytes_per_rank
+    assert i16 >= 10 * runs and runs < n // 5
 
 
 def test_mask_exchange_single_process_and_limits():
-    ex = mnd.MaskExchange(3, 4, torch.device("cpu"))
+    ex = mnd.MaskExchange(3, 4, torch.device("cpu"), fmt="int16")
     mask = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     table = torch.tensor([5, 7, -1, -1], dtype=torch.int32)
     slot = ex.submit(mask, table, 2, -3.25)

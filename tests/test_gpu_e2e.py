@@ -1,0 +1,106 @@
+"""BASELINE.json configs[3] at the reference caller's working size (egs/cityscape/local/segment.py:93:
+512 x 1024): network -> producer hand-off -> merger -> mask post-processing, all on one GPU.
+
+    PSPNet-ResNet50-shaped forward (width 64, random weights; examples/pspnet_pipeline.py)
+      -> Merger.prepare   sigmoid + bilinear resize to 512x1024 + clip  (inference_utils.py:44,96;
+                          segment.py:115-123; c_segment.pyx:53-55)
+      -> Merger.segment   the HIP merger, default (AUTO) mode            (segment.py:138)
+      -> Merger.upsample_mask  nearest-neighbour back to the image size  (segment.py:146-149)
+      -> Merger.encode_rle     COCO RLE per instance, zero-area dropped  (segment.py:165-186,
+                                                                          evaluate.py:52-54)
+The oracle runs ONCE on the same prepared maps (about 30-60 s of CPU).  A random-weight network gives
+smooth maps near 0.5 -- order-dependent inputs on which AUTO is an approximation of the reference's
+sequential order and says so (proof == 0): what is asserted is the plumbing, the invariants of the
+post-processing and a measured agreement with the reference's partition; exact equality at this size
+is a strict expected failure.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from mergenet_amd import labels, rle
+from mergenet_amd import segmenter as seg
+from mergenet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+H_SEG, W_SEG, C = 512, 1024, 9
+_cache = {}
+
+
+def _pipeline(oracle):
+    if _cache:
+        return _cache
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from pspnet_pipeline import PSPNetResNet50
+    offs = synth.generate_offsets(40, 10)
+    torch.manual_seed(7)
+    model = PSPNetResNet50(C, len(offs), width=64).cuda().eval()
+    img = torch.rand(1, 3, 384, 768, device="cuda")          # the network's own resolution
+    with torch.no_grad():
+        logits = model(img)[0].float().contiguous()          # [C + O, 384, 768]
+    # Random weights alone give maps on which everything merges into one object.  So that the rest of
+    # the chain has instances to carry, the logits of a 6-instance synth-v1 layout (at the network's
+    # resolution) are added to the network's output -- a stand-in for trained weights, which cannot
+    # be had offline; sigmoid, bilinear resize and clip then blur its boundaries as they would a
+    # real network's.
+    teacher = synth.synth_v1(384, 768, C, offs, 4242, noise=0.1, num_instances=6)
+    tp = np.concatenate([teacher.class_probs, teacher.sameness_probs]).clip(0.02, 0.98)
+    logits = (logits + torch.from_numpy(np.log(tp / (1.0 - tp)).astype(np.float32)).cuda()).contiguous()
+    merger = seg.Merger(1024, 2048, C, len(offs))
+    maps = merger.prepare(logits, H_SEG, W_SEG, apply_sigmoid=True, clip=True)
+    cp, sp = maps[:C].contiguous(), maps[C:].contiguous()
+    mask, table, _, st = merger.segment(cp, sp, offs, seg.default_options())
+    K = st["num_instances"]
+    up = merger.upsample_mask(mask, 1024, 2048)               # back to the "image" size
+    res = merger.encode_rle(up, K, drop_zero_area=True)
+    torch.cuda.synchronize()
+    ref = oracle.run_csegment(cp.cpu().numpy(), sp.cpu().numpy(), C, offs, 0.0, 1.0, 0.03)
+    _cache.update(dict(maps=maps, mask=mask.cpu().numpy(), classes=[int(c) for c in table[:K].cpu().numpy()],
+                       st=st, up=up.cpu().numpy(), rle=res, ref=ref, merger=merger, K=K))
+    return _cache
+
+
+def test_end_to_end_plumbing_and_postprocessing(oracle):
+    r = _pipeline(oracle)
+    st, mask, up = r["st"], r["mask"], r["up"]
+    assert r["maps"].shape == (C + 10, H_SEG, W_SEG)
+    assert float(r["maps"].min()) >= np.finfo(np.float32).eps and float(r["maps"].max()) <= 1.0 - np.finfo(np.float32).eps
+    assert mask.shape == (H_SEG, W_SEG) and mask.min() >= 0 and mask.max() == r["K"] == len(r["classes"])
+    assert st["status"] == 0 and st["merges"] == H_SEG * W_SEG - st["num_objects"]
+    # nearest-neighbour x2: every 2x2 block of the upsampled mask is one pixel of the mask
+    assert up.shape == (1024, 2048) and np.array_equal(up[::2, ::2], mask) and np.array_equal(up[1::2, 1::2], mask)
+    # RLE: one entry per instance that still has pixels, decodes to exactly that instance
+    present = [k for k in range(1, r["K"] + 1) if (up == k).any()]
+    assert [e["label"] for e in r["rle"]] == present
+    for e in r["rle"][:40]:
+        k = e["label"]
+        assert e["size"] == [1024, 2048] and e["area"] == int((up == k).sum()) > 0
+        assert np.array_equal(rle.decode(rle.string_to_counts(e["counts"]), 1024, 2048), up == k)
+
+
+def test_end_to_end_auto_says_unproven_and_stays_close_to_the_reference(oracle):
+    r = _pipeline(oracle)
+    st, ref = r["st"], r["ref"]
+    assert st["proof"] == 0 and st["certified"] == 0          # smooth maps: no claim of exactness
+    agree = labels.agreement(r["mask"], ref.mask)
+    frac = agree / float(H_SEG * W_SEG)
+    print("end-to-end 512x1024: mode_used %d, %d instances (reference %d), %.4f of the pixels agree with the "
+          "reference's partition, log-likelihood rel. diff %.2e"
+          % (st["mode_used"], r["K"], len(ref.object_class), frac,
+             abs(st["total_logprob"] - ref.total_logprob) / abs(ref.total_logprob)))
+    # the log-likelihood of whatever partition AUTO returns is evaluated exactly (A.4 of SURVEY.md):
+    # compare with the oracle's evaluation of ITS partition only loosely (different partitions)
+    assert abs(st["total_logprob"] - ref.total_logprob) <= 2e-2 * abs(ref.total_logprob)
+    assert frac >= 0.90
+
+
+@pytest.mark.xfail(strict=True, reason="known gap at the reference caller's size: network maps are smooth and "
+                   "order-dependent, AUTO falls to the parallel rounds, an approximation of the reference's "
+                   "sequential order (DESIGN.md section 5); EXACT mode is only affordable for small images")
+def test_end_to_end_equals_the_reference_exactly(oracle):
+    r = _pipeline(oracle)
+    assert labels.masks_equivalent(r["mask"], r["classes"], r["ref"].mask, r["ref"].object_class)

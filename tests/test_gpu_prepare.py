@@ -230,3 +230,58 @@ def test_segment_async_two_contexts_one_stream_equals_segment():
         a.segment(cases[1][0], cases[1][1], offs, opts)
     assert p.result()[3]["num_instances"] == want[0][3]["num_instances"]
     a.close(); b.close()
+
+
+def test_run_length_wire_device_equals_cpu_twin_and_round_trips():
+    """mn_pack_runs_device / mn_unpack_runs_device (the default wire of the multi-GPU mask exchange)
+    against the CPU twins in mergenet_amd.distributed, on a real 1024x2048 result mask (24 instances)
+    and on a small ragged one; plus the overflow report for a mask with too many label changes."""
+    import os
+    import torch
+    import golden_util as gu
+    from mergenet_amd import distributed as mnd
+    from mergenet_amd import segmenter as seg
+    z = np.load(os.path.join(gu.GOLDEN, "cseg_synth_1024x2048_cfg2.npz"))
+    cases = [(z["mask"].astype(np.int32), [int(c) for c in z["object_class"]])]
+    rng = np.random.default_rng(3)
+    small = np.repeat(np.repeat(rng.integers(0, 5, (5, 9)), 7, 0), 11, 1)[:33, :97].astype(np.int32)
+    cases.append((small, [1, 2, 3, 4]))
+    for mask_np, classes in cases:
+        H, W = mask_np.shape
+        merger = seg.Merger(H, W, 9, 10)
+        try:
+            cap = max(mnd.runs_capacity(H * W), 2048)
+            k = len(classes)
+            mask = torch.from_numpy(mask_np).cuda()
+            table = torch.full((H * W,), -1, dtype=torch.int32, device="cuda")
+            table[:k] = torch.tensor(classes, dtype=torch.int32, device="cuda")
+            wire = torch.zeros(seg.runs_wire_words(cap, mnd.MAX_INSTANCES), dtype=torch.int32, device="cuda")
+            seg.pack_runs(merger, mask, table, k, wire, cap, mnd.MAX_INSTANCES, -4321.125)
+            ref = mnd.pack_runs_cpu(torch.from_numpy(mask_np), table.cpu(), k, -4321.125, cap)
+            n = int(ref[0])
+            got = wire.cpu()
+            assert int(got[0]) == n and n > 0
+            assert torch.equal(got[:4 + n], ref[:4 + n])                                   # header + positions
+            lab_g = got[4 + cap: 4 + cap + (cap + 1) // 2].view(torch.int16)[:n]
+            lab_r = ref[4 + cap: 4 + cap + (cap + 1) // 2].view(torch.int16)[:n]
+            assert torch.equal(lab_g, lab_r)
+            assert torch.equal(got[4 + cap + (cap + 1) // 2:], ref[4 + cap + (cap + 1) // 2:])   # classes
+            m2, t2 = seg.unpack_runs(wire, H, W, cap, mnd.MAX_INSTANCES)
+            assert torch.equal(m2.cpu(), torch.from_numpy(mask_np))
+            assert t2[:k].cpu().tolist() == classes and bool((t2[k:] == -1).all())
+            if H * W > 100000:
+                assert 10 * wire.numel() * 4 <= 2 * H * W + 2 * (mnd.MAX_INSTANCES + 5) + 40 * 1024   # >= 10x below int16
+        finally:
+            merger.close()
+    # too many changes for the capacity: reported in the header, not written past the buffer
+    H, W = 64, 64
+    merger = seg.Merger(H, W, 3, 2)
+    try:
+        noisy = torch.from_numpy(rng.integers(0, 7, (H, W)).astype(np.int32)).cuda()
+        cap = 128
+        wire = torch.zeros(seg.runs_wire_words(cap, 16) + 8, dtype=torch.int32, device="cuda")
+        wire[-8:] = 777
+        seg.pack_runs(merger, noisy, torch.zeros(16, dtype=torch.int32, device="cuda"), 3, wire, cap, 16, 0.0)
+        assert int(wire[0]) == -1 and bool((wire[-8:] == 777).all())
+    finally:
+        merger.close()
