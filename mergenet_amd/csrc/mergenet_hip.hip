@@ -478,16 +478,23 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
 // and the verdict is read by the caller at the end.
 template <int PX>
 static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
-                         u64* neg_list, unsigned sub_cap) {
+                         u64* neg_list, unsigned sub_cap, bool cls = false) {
   const int N = P.N, ngroups = (N + PX - 1) / PX;
   if (!hook) {
     const dim3 g(grid_for(ngroups, MN_CC_SIGN_THREADS)), b(MN_CC_SIGN_THREADS);
-    if (!P.clip && P.sdb == 0.0f)
-      hipLaunchKernelGGL((mn_cc_sign<PX, true>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt,
-                         c->scalars + 6, c->partial);
-    else
-      hipLaunchKernelGGL((mn_cc_sign<PX, false>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt,
-                         c->scalars + 6, c->partial);
+    ClsOut CO;
+    CO.ocls = c->ocls; CO.cls0 = c->cls0; CO.lpvalid = c->lpvalid;
+    CO.gsum = reinterpret_cast<int*>(c->lpsum);     // (the summed class log-probs are written later, at roots only)
+    CO.gstride = (size_t)P.N;
+    const bool plain = !P.clip && P.sdb == 0.0f;
+#define MN_LAUNCH_SIGN(PLAINV, CLSV)                                                                    \
+    hipLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, \
+                       c->cc_negcnt, c->scalars + 6, c->partial, CO)
+    if (plain && cls) MN_LAUNCH_SIGN(true, true);
+    else if (plain) MN_LAUNCH_SIGN(true, false);
+    else if (cls) MN_LAUNCH_SIGN(false, true);
+    else MN_LAUNCH_SIGN(false, false);
+#undef MN_LAUNCH_SIGN
   } else {
     const dim3 gx(8 * ((grid_for(ngroups, 256) + 7) / 8));
     hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kmask);
@@ -519,7 +526,9 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   int* clsmax = c->mapbuf;
   // (ev[0], recorded by run_phase_a right before, is the start of the sweep: every event on the
   // caller's stream costs a ~6 us dispatch gap)
-  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap);
+  // the sweep takes the class planes too when a lane's four pixels are four pixels of the image
+  const bool fused_cls = four && (N & 3) == 0;
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
   if (!few_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // (labelling the tiles inside the sign sweep -- a block = a 16 x 64 tile -- was tried: 40.6 us for
@@ -548,11 +557,18 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (lds > c->cc_sum_lds) {
       MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_class_sums),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_sums),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       c->cc_sum_lds = lds;
     }
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
-    hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
-                       c->lp_acc, clsmin, clsmax);
+    if (fused_cls)
+      hipLaunchKernelGGL(mn_cc_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
+                         (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), (size_t)P.N,
+                         c->lp_acc, clsmin, clsmax);
+    else
+      hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
+                         c->lp_acc, clsmin, clsmax);
   }
   if (!few_events) MN_HIP(hipEventRecord(c->ev[8], st));
   if (fork_after_sums) {

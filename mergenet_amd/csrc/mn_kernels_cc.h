@@ -96,10 +96,72 @@ __device__ __forceinline__ float mn_cc_value(const ImgParams& P, float v) {
   return PLAIN ? v : mn_same_value(P, v);
 }
 
-template <int PX, bool PLAIN>
+// CLS (PX == 4, N % 4 == 0): the lane also streams the C class planes of its four pixels first -- the
+// affinity-scoring sweep then reads every input tensor, class and sameness, exactly once:
+// 4 * (C + O) bytes per pixel (159.4 MB at 1024x2048, C = 9, O = 10).  Per pixel the arg-max class
+// (first maximum of logf, settled on the values with an exact tie check: mn_cc_class_part), per
+// lane and class ONE log of the product of the four values (2^-24 fixed point, gsum[c][lane]): what
+// the class sums of the components need, 9 B/pixel instead of the 36 B/pixel planes (mn_cc_sums).
+struct ClsOut {
+  unsigned char* ocls; unsigned char* cls0; unsigned char* lpvalid; int* gsum; size_t gstride;
+};
+
+// first maximum of logf over the classes of one pixel (Object::Object, segment.cc:5-21)
+__device__ __forceinline__ int mn_cc_argmax_logf(const ImgParams& P, int p) {
+  float best = 0.0f;
+  int b = 0;
+  for (int c = 0; c < P.C; c++) {
+    const float l = logf(mn_ld_class(P, c, p));
+    if (c == 0 || l > best) { best = l; b = c; }
+  }
+  return b;
+}
+
+__device__ __forceinline__ void mn_cc_class_part(const ImgParams& P, const ClsOut& CO, int i) {
+  // The arg-max is taken on the VALUES (logf is monotone); the reference's first-maximum rule on
+  // logf values differs only if a class of LOWER index lies within rounding distance of the maximum
+  // (logf may map both to one float): `prev` keeps the largest value below the current best's index
+  // and such pixels redo their arg-max with logf.  Values are >= 2^-23 after the binding's clip, so
+  // the product of four stays above 2^-92 (relative error 2e-7, far below the float32 accumulation
+  // of the reference it stands for).
+  float4 best, prev = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+  int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
+  for (int c = 0; c < P.C; c++) {
+    float4 v = nxt;
+    if (c + 1 < P.C)
+      nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
+    if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
+    if (c == 0) {
+      best = v;
+    } else {
+      if (v.x > best.x) { prev.x = best.x; best.x = v.x; b0 = c; }
+      if (v.y > best.y) { prev.y = best.y; best.y = v.y; b1 = c; }
+      if (v.z > best.z) { prev.z = best.z; best.z = v.z; b2 = c; }
+      if (v.w > best.w) { prev.w = best.w; best.w = v.w; b3 = c; }
+    }
+    // float * 2^24 is exact: the term is the exact product rounded to the nearest integer
+    CO.gsum[(size_t)c * CO.gstride + i] = __float2int_rn(logf((v.x * v.y) * (v.z * v.w)) * 16777216.0f);
+  }
+  // a lower class within 2^-18 of the maximum (logs of magnitude < 16 are 2^-20 apart at most, and
+  // the GPU's logf is within an ulp of libm's): settle it the reference's way
+  const float near = 1.0f - 3.814697265625e-06f;
+  if (prev.x >= best.x * near) b0 = mn_cc_argmax_logf(P, 4 * i);
+  if (prev.y >= best.y * near) b1 = mn_cc_argmax_logf(P, 4 * i + 1);
+  if (prev.z >= best.z * near) b2 = mn_cc_argmax_logf(P, 4 * i + 2);
+  if (prev.w >= best.w * near) b3 = mn_cc_argmax_logf(P, 4 * i + 3);
+  uchar4 o;
+  o.x = (unsigned char)b0; o.y = (unsigned char)b1; o.z = (unsigned char)b2; o.w = (unsigned char)b3;
+  *reinterpret_cast<uchar4*>(CO.ocls + 4 * (size_t)i) = o;
+  *reinterpret_cast<uchar4*>(CO.cls0 + 4 * (size_t)i) = o;
+  *reinterpret_cast<uchar4*>(CO.lpvalid + 4 * (size_t)i) = make_uchar4(0, 0, 0, 0);
+}
+
+template <int PX, bool PLAIN, bool CLS>
 __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
     ImgParams P, unsigned* __restrict__ bits, u64* __restrict__ neg_list, unsigned sub_cap,
-    unsigned* __restrict__ neg_count, int* __restrict__ violations, double* __restrict__ partial) {
+    unsigned* __restrict__ neg_count, int* __restrict__ violations, double* __restrict__ partial,
+    ClsOut CO) {
   __shared__ double s_part[MN_CC_SIGN_THREADS / 64];
   __shared__ int s_w[MN_CC_SIGN_THREADS / 64];
   __shared__ unsigned short s_item[MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS > 10240
@@ -111,6 +173,7 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
   const bool live = i < ngroups;
   const int p0 = live ? PX * i : 0;
   const int r = p0 / P.W, c0 = p0 - r * P.W;
+  if constexpr (CLS) { if (live) mn_cc_class_part(P, CO, i); }
   float f = 1.0f;
   double t_sum = 0.0;
   unsigned m[PX], ng[PX];                                // positive / negative out-edges per pixel
@@ -530,17 +593,6 @@ __device__ __forceinline__ void mn_cc_cls(int* s_min, int* s_max, int* __restric
   }
 }
 
-// first maximum of logf over the classes of one pixel (Object::Object, segment.cc:5-21)
-__device__ __forceinline__ int mn_cc_argmax_logf(const ImgParams& P, int p) {
-  float best = 0.0f;
-  int b = 0;
-  for (int c = 0; c < P.C; c++) {
-    const float l = logf(mn_ld_class(P, c, p));
-    if (c == 0 || l > best) { best = l; b = c; }
-  }
-  return b;
-}
-
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     ImgParams P, ObjState S, unsigned char* __restrict__ cls0, i64* __restrict__ lp_acc,
     int* __restrict__ clsmin, int* __restrict__ clsmax) {
@@ -665,6 +717,149 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_class_sums(
     S.ocls[p] = (unsigned char)b;
     cls0[p] = (unsigned char)b;
     mn_cc_cls(s_min, s_max, clsmin, clsmax, root, -1, b, b);
+  }
+  __syncthreads();
+  if (threadIdx.x < MN_CC_SUM_SLOTS && s_root[threadIdx.x] >= 0) {
+    atomicMin(&clsmin[s_root[threadIdx.x]], s_min[threadIdx.x]);
+    atomicMax(&clsmax[s_root[threadIdx.x]], s_max[threadIdx.x]);
+  }
+  for (int j = threadIdx.x; j < nval; j += MN_CC_SUM_THREADS) {
+    const u64 v = s_val[j];
+    if (v == 0) continue;
+    const int slot = j / (P.C + 1), c = j - slot * (P.C + 1);
+    mn_cc_add(P, S, s_root, s_val, lp_acc, s_root[slot], c, -1, (i64)v);
+  }
+}
+
+
+
+// Sum of a 64-bit value over the 16 lanes of a DPP row (all 16 lanes get it): quad_perm xor 1, xor 2,
+// then row_half_mirror and row_mirror -- data-parallel-primitive moves on the VALU, no LDS crossbar
+// (a ds_bpermute-based __shfl_xor costs about what the atomics it is meant to save cost).
+__device__ __forceinline__ i64 mn_row16_sum(i64 x) {
+  int lo = (int)(x & 0xFFFFFFFFll), hi = (int)(x >> 32);
+#define MN_DPP_STEP(CTRL)                                                                   \
+  {                                                                                         \
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);              \
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);              \
+    const i64 y = ((i64)hi << 32 | (i64)(unsigned)lo) + ((i64)hi2 << 32 | (i64)(unsigned)lo2); \
+    lo = (int)(y & 0xFFFFFFFFll); hi = (int)(y >> 32);                                      \
+  }
+  MN_DPP_STEP(0xB1)     // quad_perm [1,0,3,2]
+  MN_DPP_STEP(0x4E)     // quad_perm [2,3,0,1]
+  MN_DPP_STEP(0x141)    // row_half_mirror
+  MN_DPP_STEP(0x140)    // row_mirror
+#undef MN_DPP_STEP
+  return (i64)hi << 32 | (i64)(unsigned)lo;
+}
+
+__device__ __forceinline__ int mn_row16_min(int x) {
+  x = min(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
+  return x;
+}
+
+// one class plane of a lane whose four pixels lie in different components: per-pixel logs
+__device__ __noinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const ObjState& S, int* s_root,
+                                                  u64* s_val, i64* __restrict__ lp_acc, int4 r, int c,
+                                                  int s0, int s1, int s2, int s3, float4 v) {
+  const float vx = P.clip ? mn_clip(v.x) : v.x, vy = P.clip ? mn_clip(v.y) : v.y;
+  const float vz = P.clip ? mn_clip(v.z) : v.z, vw = P.clip ? mn_clip(v.w) : v.w;
+  mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c, s0, (i64)__float2int_rn(logf(vx) * (float)MN_LP_FIX));
+  mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, c, s1, (i64)__float2int_rn(logf(vy) * (float)MN_LP_FIX));
+  mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, c, s2, (i64)__float2int_rn(logf(vz) * (float)MN_LP_FIX));
+  mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, c, s3, (i64)__float2int_rn(logf(vw) * (float)MN_LP_FIX));
+}
+
+// Class sums of the components from what the sweep left (CLS form of mn_cc_sign): per lane and
+// class the fixed-point log of the product of its four values, per pixel the arg-max class.  A lane
+// whose four pixels share a component -- nearly all -- adds its C numbers and its class range to
+// the block's LDS table; a lane across a component boundary goes back to the class planes for
+// per-pixel logs.  Leaves parent[] flat.  9 B/pixel read instead of the 36 B/pixel planes.
+__global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
+    ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ gsum,
+    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
+  u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
+  __shared__ int s_root[MN_CC_SUM_SLOTS];
+  __shared__ int s_min[MN_CC_SUM_SLOTS];
+  __shared__ int s_max[MN_CC_SUM_SLOTS];
+  const int nval = MN_CC_SUM_SLOTS * (P.C + 1);
+  for (int i = threadIdx.x; i < nval; i += MN_CC_SUM_THREADS) s_val[i] = 0;
+  if (threadIdx.x < MN_CC_SUM_SLOTS) { s_root[threadIdx.x] = -1; s_min[threadIdx.x] = 255; s_max[threadIdx.x] = 0; }
+  __syncthreads();
+  const int n4 = P.N >> 2;
+  const int i = blockIdx.x * MN_CC_SUM_THREADS + threadIdx.x;
+  if (i < n4) {
+    int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
+    const uchar4 b = *reinterpret_cast<const uchar4*>(cls0 + 4 * (size_t)i);
+    // after the hook stage a parent may still be one or two steps from its root
+    r.x = mn_cc_root_ro(S.parent, r.x);
+    r.y = r.y == r.x ? r.x : mn_cc_root_ro(S.parent, r.y);
+    r.z = r.z == r.x ? r.x : mn_cc_root_ro(S.parent, r.z);
+    r.w = r.w == r.x ? r.x : mn_cc_root_ro(S.parent, r.w);
+    *reinterpret_cast<int4*>(S.parent + 4 * (size_t)i) = r;
+    const bool same = r.x == r.y && r.x == r.z && r.x == r.w;
+    const int s0 = mn_lds_root_slot(s_root, r.x);
+    // a wave inside one component -- most are -- would put 64 atomics on ONE LDS address per class,
+    // and same-address LDS atomics run one after the other (this, not the plane traffic, was what
+    // the class sums cost): its 16-lane rows are summed on the VALU first, 4 atomics per class
+    const bool uni = __all(same && r.x == __shfl(r.x, 0) && (blockIdx.x + 1) * MN_CC_SUM_THREADS <= n4);
+    if (uni) {
+      const int lane = threadIdx.x & 63;
+      constexpr int G = 3;                                // gsum loads in flight together
+      for (int c0 = 0; c0 < P.C; c0 += G) {
+        int g[G];
+#pragma unroll
+        for (int a = 0; a < G; a++) g[a] = c0 + a < P.C ? gsum[(size_t)(c0 + a) * gstride + i] : 0;
+#pragma unroll
+        for (int a = 0; a < G; a++) {
+          if (c0 + a >= P.C) break;
+          const i64 rs = mn_row16_sum((i64)g[a]);
+          if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, rs);
+        }
+      }
+      if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 64);
+      const int lo = mn_row16_min(min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w)));
+      const int hi = -mn_row16_min(-max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w)));
+      if ((lane & 15) == 0) mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo, hi);
+    } else if (same) {
+      constexpr int G = 3;                                // gsum loads in flight together
+      for (int c0 = 0; c0 < P.C; c0 += G) {
+        int g[G];
+#pragma unroll
+        for (int a = 0; a < G; a++) g[a] = c0 + a < P.C ? gsum[(size_t)(c0 + a) * gstride + i] : 0;
+#pragma unroll
+        for (int a = 0; a < G; a++)
+          if (c0 + a < P.C) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, (i64)g[a]);
+      }
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w)),
+                max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w)));
+    } else {
+      const int s1 = mn_lds_root_slot(s_root, r.y), s2 = mn_lds_root_slot(s_root, r.z), s3 = mn_lds_root_slot(s_root, r.w);
+      // (the planes are cold again by now: three of them per round trip, not one -- the few waves
+      // that hold such a lane were the whole tail of the kernel, nine HBM latencies long)
+      for (int c0 = 0; c0 < P.C; c0 += 3) {
+        const int c1 = min(c0 + 1, P.C - 1), c2 = min(c0 + 2, P.C - 1);
+        const float4 va = *reinterpret_cast<const float4*>(P.cls + (size_t)c0 * P.N + 4 * (size_t)i);
+        const float4 vb = *reinterpret_cast<const float4*>(P.cls + (size_t)c1 * P.N + 4 * (size_t)i);
+        const float4 vc = *reinterpret_cast<const float4*>(P.cls + (size_t)c2 * P.N + 4 * (size_t)i);
+        mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0, s0, s1, s2, s3, va);
+        if (c0 + 1 < P.C) mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0 + 1, s0, s1, s2, s3, vb);
+        if (c0 + 2 < P.C) mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0 + 2, s0, s1, s2, s3, vc);
+      }
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, P.C, s1, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, P.C, s2, 1);
+      mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, P.C, s3, 1);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, b.x, b.x);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.y, s1, b.y, b.y);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.z, s2, b.z, b.z);
+      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.w, s3, b.w, b.w);
+    }
   }
   __syncthreads();
   if (threadIdx.x < MN_CC_SUM_SLOTS && s_root[threadIdx.x] >= 0) {

@@ -145,18 +145,24 @@ def test_pack_wire_matches_layout():
         seg.pack_wire(mask, table, mnd.MAX_INSTANCES + 1, wire, mnd.MAX_INSTANCES)
 
 
-def test_mask_exchange_single_gpu_uses_the_pack_kernel():
-    """MaskExchange on device tensors without a process group: wire packed by the HIP kernel,
-    results come back as int16 views of the receive buffer."""
+@pytest.mark.parametrize("fmt", ["runs", "int16"])
+def test_mask_exchange_single_gpu_uses_the_pack_kernel(fmt):
+    """MaskExchange on device tensors without a process group: wire packed (and, for the run-length
+    format, unpacked) by the HIP kernels; both formats deliver the same mask, table, count, log-likelihood."""
     import torch
     from mergenet_amd import distributed as mnd
+    from mergenet_amd import segmenter as seg
     H, W, K = 33, 47, 5
-    g = torch.Generator().manual_seed(7)
-    mask = torch.randint(0, K + 1, (H, W), generator=g, dtype=torch.int32).cuda()
+    mask = torch.zeros((H, W), dtype=torch.int32)
+    mask[3:8, 5:30] = 2                 # ~35 row-major label changes: within the 64 a 33x47 wire holds
+    mask[10:20, 25:47] = 5
+    mask[0, 0] = 1
+    mask = mask.cuda()
     table = torch.full((H * W,), -1, dtype=torch.int32)
     table[:K] = torch.tensor([3, 1, 4, 1, 5], dtype=torch.int32)
     table = table.cuda()
-    ex = mnd.MaskExchange(H, W, torch.device("cuda", 0))
+    merger = seg.Merger(H, W, 3, 2)
+    ex = mnd.MaskExchange(H, W, torch.device("cuda", 0), fmt=fmt, merger=merger)
     slots = [ex.submit(mask, table, K, -77.125) for _ in range(3)]     # reuses both buffers
     masks, tabs, counts = ex.result(slots[-1])
     torch.cuda.synchronize()
@@ -164,6 +170,7 @@ def test_mask_exchange_single_gpu_uses_the_pack_kernel():
     assert tabs[0, :K].tolist() == [3, 1, 4, 1, 5] and bool((tabs[0, K:] == -1).all())
     assert int(counts[0]) == K and ex.logprobs(slots[-1]).tolist() == [-77.125]
     ex.drain()
+    merger.close()
 
 
 def test_merger_pool_equals_serial_merger_and_keeps_order():
