@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
+    ap.add_argument("--contexts", type=int, default=4,
+                    help="merger contexts in rotation on the one compute stream (launch of image i precedes the "
+                         "read-back of image i - contexts + 1)")
     ap.add_argument("--wire", default="runs", choices=["runs", "int16"],
                     help="wire format of the mask exchange for N > 1 (run-length change points | int16 map)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -144,7 +147,8 @@ def main():
     # contention, not the kernels; the pipelined rate is reported beside the line (`pipelined`).
     depth = max(1, args.pipeline)
     merger = seg.Merger(H, W, C, O, device=local_rank)
-    mergers2 = [merger, seg.Merger(H, W, C, O, device=local_rank)]
+    # contexts in rotation on ONE stream: image i is launched before image i - CONTEXTS + 1 is read back
+    mergers_ring = [merger] + [seg.Merger(H, W, C, O, device=local_rank) for _ in range(max(1, args.contexts) - 1)]
     main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode,
@@ -174,18 +178,18 @@ def main():
             last = (mask, table, st, slot)
 
         if pool is None:
-            # one stream, two contexts: the launch of step i+1 precedes the read-back of step i,
-            # so the host round trip of an image is hidden while kernels of different images
-            # still run one after the other (their HIP-event durations stay those of the kernels)
-            prev = None
+            # one stream, a ring of contexts: image i is launched before image i - contexts + 1 is read
+            # back, so the host never waits for the tail of an image (a latency chain of ~0.2 ms on the
+            # context's side stream) while the sweeps of different images still run one after the
+            # other on the one compute stream (their HIP-event durations stay those of the kernels)
+            ring = deque()
             for i in range(first, first + count):
                 cp, sp = pool_images[i % POOL]
-                cur = mergers2[i % 2].segment_async(cp, sp, offs, opts)
-                if prev is not None:
-                    collect(prev.result())
-                prev = cur
-            if prev is not None:
-                collect(prev.result())
+                ring.append(mergers_ring[i % len(mergers_ring)].segment_async(cp, sp, offs, opts))
+                if len(ring) >= len(mergers_ring):
+                    collect(ring.popleft().result())
+            while ring:
+                collect(ring.popleft().result())
         else:
             window = deque()
             for i in range(first, first + count):
@@ -299,7 +303,7 @@ def main():
     if rank == 0:
         plane_bytes = 4.0 * H * W
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_components_1024x2048.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_components_1024x2048.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh).get("hbm_bytes_per_launch", {})
@@ -310,23 +314,27 @@ def main():
                     "avg_launch_ms": round(ms, 5), "achieved": round(gbs, 2),
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name)}
 
-        if avg["ms_cc_sums"] > 0:      # components mode: labelling, then one sweep per plane kind
-            passes = [price("mn_cc_sign", avg["ms_cc_edges"], O, "O sameness planes (the only read of them)"),
-                      price("mn_cc_class_sums", avg["ms_cc_sums"], C, "C class planes"),
+        if avg["ms_cc_sums"] > 0:      # components mode
+            # the affinity-scoring sweep (mn_cc_sign, class-plane form) reads EVERY input plane once:
+            # 4 * (C + O) bytes per pixel; everything after it works on what
+            # it leaves (4 B/pixel edge masks, 9 B/pixel class log-products, the negative-edge list)
+            passes = [price("mn_cc_sign", avg["ms_cc_edges"], C + O,
+                            "C class planes + O sameness planes (the only read of the input tensors)"),
                       price("mn_cc_tiles+mn_cc_borders+mn_cc_flatten+mn_cc_hook", avg["ms_cc_label"], 1,
-                            "the 4 B/pixel edge masks (union-find: latency-bound, no roofline claim)")]
-        else:
-            passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
-                      price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]
-        single = [p for p in passes if "+" not in p["kernel"]]
-        dom = max(single, key=lambda p: p["avg_launch_ms"])
+                            "the 4 B/pixel edge masks (union-find: latency-bound, no roofline claim)"),
+                      price("mn_cc_sums", avg["ms_cc_sums"], (C + 5) / 4.0,
+                            "per-lane class log-products + roots + arg-max classes, C + 5 B/pixel "
+                            "(dependent round trips, no roofline claim; on the side stream)")]
+        streaming = [p for p in passes if "no roofline claim" not in p["reads"]]
+        dom = max(streaming, key=lambda p: p["avg_launch_ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
                     "algorithmic_bytes": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_launch_ms"],
                     "timing": "hipEvent pairs on the launch stream around the kernel, inside the "
                               "timed steps (includes the ~5 us dispatch gap; rocprofv3 kernel-only "
-                              "durations are in profiles/r01_bench_kernel_stats.csv)",
-                    "why_this_kernel": "slowest single streaming kernel of the timed path"}
+                              "durations are in profiles/r02_bench_kernel_stats.csv)",
+                    "why_this_kernel": "the one HBM-streaming kernel of the timed path: it reads every input "
+                                       "plane (class + sameness) exactly once"}
         out = {
             "metric": "merged Mpixels/sec at 1024x2048",
             "value": round(world * args.steps * H * W / elapsed / 1e6, 4),
@@ -346,9 +354,13 @@ def main():
                                    "in rotation)" % POOL,
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
                        "pipeline_depth": depth,
-                       "host_overlap": "launch of step i+1 queued before the read-back of step i "
-                                       "(mn_segment_launch / mn_segment_finish, two contexts, ONE "
-                                       "stream: kernels of different images do not overlap)",
+                       "host_overlap": "launch of step i queued before the read-back of step i - %d "
+                                       "(mn_segment_launch / mn_segment_finish, %d contexts in rotation on "
+                                       "ONE compute stream: the sweeps of different images run one after the "
+                                       "other; the latency-bound tail of an image -- class sums from the "
+                                       "sweep's products, records, second phase, labels, mask -- runs on its "
+                                       "context's side stream beside the next images' sweeps)"
+                                       % (len(mergers_ring) - 1, len(mergers_ring)),
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
                        "exchange": ("one all_gather per step of the masks (%s wire) + class tables + "

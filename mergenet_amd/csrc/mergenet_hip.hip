@@ -502,7 +502,7 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
 }
 
 static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bool wait, bool with_ball,
-                          bool with_compact, bool fork_after_sums) {
+                          bool with_compact, bool fork_before_sums) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256);
@@ -551,6 +551,15 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // caller's fill
   HashTab T = c->T;
   T.mask = (unsigned)(c->cc_cap - 1);
+  if (fork_before_sums) {
+    // From here on the image is latency-bound work of a few workgroups (and one pixel-wide mask
+    // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
+    // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
+    // for the side stream; nothing of this image is left on the caller's stream after this point.
+    MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    st = c->side;
+  }
   if (!few_events) MN_HIP(hipEventRecord(c->ev[7], st));
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
@@ -563,23 +572,14 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     }
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
     if (fused_cls)
-      hipLaunchKernelGGL(mn_cc_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
+      hipLaunchKernelGGL(mn_cc_sums, dim3((blocks + MN_CC_SUMS_ITERS - 1) / MN_CC_SUMS_ITERS), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
                          (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), (size_t)P.N,
-                         c->lp_acc, clsmin, clsmax);
+                         c->lp_acc, clsmin, clsmax, getenv("MN_DBG_SUMS") ? reinterpret_cast<long long*>(c->partial + 8192) : (long long*)nullptr);
     else
       hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
                          c->lp_acc, clsmin, clsmax);
   }
   if (!few_events) MN_HIP(hipEventRecord(c->ev[8], st));
-  if (fork_after_sums) {
-    // From here on the image is latency-bound work of a few workgroups (and one pixel-wide mask
-    // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
-    // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
-    // for the side stream; nothing of this image is left on the caller's stream after this point.
-    MN_HIP(hipEventRecord(c->ev_fork, st));
-    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    st = c->side;
-  }
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
                      (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
                      c->scalars + 6, c->cc_tcount);
@@ -992,6 +992,16 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
     else
       rc = MN_ERR_UNPROVEN;
     if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
+  }
+  if (getenv("MN_DBG_SUMS")) {
+    static long long h[6 * 600];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, c->partial + 8192, sizeof(h), hipMemcpyDeviceToHost);
+    long long t0min = h[0], tend = 0; double a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0; int nb = 256;
+    for (int b = 0; b < nb; b++) { if (h[6*b] < t0min) t0min = h[6*b]; if (h[6*b+5] > tend) tend = h[6*b+5]; }
+    long long lastt0 = 0;
+    for (int b = 0; b < nb; b++) { a1 += h[6*b+1]-h[6*b]; a2 += h[6*b+2]-h[6*b+1]; a3 += h[6*b+3]-h[6*b+2]; a4 += h[6*b+4]-h[6*b+3]; a5 += h[6*b+5]-h[6*b+4]; if (h[6*b]-t0min > lastt0) lastt0 = h[6*b]-t0min; }
+    fprintf(stderr, "sums dbg (10 ns ticks): span %lld, last block start +%lld, avg init %.0f main %.0f wait %.0f queue %.0f flush %.0f\n", tend - t0min, lastt0, a1/nb, a2/nb, a3/nb, a4/nb, a5/nb);
   }
   if (stats) *stats = q.stats;
   q.active = 0;

@@ -551,6 +551,12 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
 #ifndef MN_CC_SUM_THREADS
 #define MN_CC_SUM_THREADS 1024
 #endif
+#ifndef MN_CC_SUMS_G
+#define MN_CC_SUMS_G 9         /* class sums of a lane requested together (mn_cc_sums) */
+#endif
+#ifndef MN_CC_SUMS_ITERS
+#define MN_CC_SUMS_ITERS 1     /* chunks of 4096 pixels per block of mn_cc_sums */
+#endif
 #ifndef MN_CC_SUM_AHEAD
 #define MN_CC_SUM_AHEAD 1   /* planes in flight ahead of the one in use: 1 at 1024 threads measured best (37.3 us by events; 2: 41.4, 3: 42.4; 512 threads: 43.7 / 40.8; 256: 47.6) -- occupancy matters more */
 #endif
@@ -762,7 +768,7 @@ __device__ __forceinline__ int mn_row16_min(int x) {
 }
 
 // one class plane of a lane whose four pixels lie in different components: per-pixel logs
-__device__ __noinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const ObjState& S, int* s_root,
+__device__ __forceinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const ObjState& S, int* s_root,
                                                   u64* s_val, i64* __restrict__ lp_acc, int4 r, int c,
                                                   int s0, int s1, int s2, int s3, float4 v) {
   const float vx = P.clip ? mn_clip(v.x) : v.x, vy = P.clip ? mn_clip(v.y) : v.y;
@@ -780,21 +786,37 @@ __device__ __noinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const ObjS
 // per-pixel logs.  Leaves parent[] flat.  9 B/pixel read instead of the 36 B/pixel planes.
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ gsum,
-    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax) {
+    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax,
+    long long* __restrict__ dbg) {
+  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
   __shared__ int s_root[MN_CC_SUM_SLOTS];
   __shared__ int s_min[MN_CC_SUM_SLOTS];
   __shared__ int s_max[MN_CC_SUM_SLOTS];
+  __shared__ int s_q[MN_CC_SUM_THREADS * MN_CC_SUMS_ITERS];      // (a lane queues at most once per chunk)
+  __shared__ int s_qn;
   const int nval = MN_CC_SUM_SLOTS * (P.C + 1);
   for (int i = threadIdx.x; i < nval; i += MN_CC_SUM_THREADS) s_val[i] = 0;
+  if (threadIdx.x == 0) s_qn = 0;
   if (threadIdx.x < MN_CC_SUM_SLOTS) { s_root[threadIdx.x] = -1; s_min[threadIdx.x] = 255; s_max[threadIdx.x] = 0; }
   __syncthreads();
+  const long long dbg_t1 = dbg ? (long long)wall_clock64() : 0;
   const int n4 = P.N >> 2;
-  const int i = blockIdx.x * MN_CC_SUM_THREADS + threadIdx.x;
+  // grid-stride: MN_CC_SUMS_ITERS chunks per block, so that the block's table is flushed -- global
+  // atomics on the few hot words of the large components -- once per several thousand pixels more
+  for (int base = blockIdx.x * MN_CC_SUM_THREADS; base < n4; base += gridDim.x * MN_CC_SUM_THREADS) {
+  const int i = base + (int)threadIdx.x;
   if (i < n4) {
+    // every load of the lane that does not depend on another is requested first -- parents, arg-max
+    // classes and the first MN_CC_SUMS_G class sums: the kernel is a chain of dependent round trips
+    // (parent -> root -> ...), not a stream, and these used to queue up behind the chase
+    constexpr int G = MN_CC_SUMS_G;
     int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
     const uchar4 b = *reinterpret_cast<const uchar4*>(cls0 + 4 * (size_t)i);
+    int g[G];
+#pragma unroll
+    for (int a = 0; a < G; a++) g[a] = a < P.C ? gsum[(size_t)a * gstride + i] : 0;
     // after the hook stage a parent may still be one or two steps from its root
     r.x = mn_cc_root_ro(S.parent, r.x);
     r.y = r.y == r.x ? r.x : mn_cc_root_ro(S.parent, r.y);
@@ -804,63 +826,74 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     const bool same = r.x == r.y && r.x == r.z && r.x == r.w;
     const int s0 = mn_lds_root_slot(s_root, r.x);
     // a wave inside one component -- most are -- would put 64 atomics on ONE LDS address per class,
-    // and same-address LDS atomics run one after the other (this, not the plane traffic, was what
-    // the class sums cost): its 16-lane rows are summed on the VALU first, 4 atomics per class
-    const bool uni = __all(same && r.x == __shfl(r.x, 0) && (blockIdx.x + 1) * MN_CC_SUM_THREADS <= n4);
-    if (uni) {
+    // and same-address LDS atomics run one after the other: its 16-lane rows are summed on the VALU
+    // first, 4 atomics per class
+    const bool uni = __all(same && r.x == __shfl(r.x, 0) && i - (int)(threadIdx.x & 63) + 63 < n4);
+    if (same) {
       const int lane = threadIdx.x & 63;
-      constexpr int G = 3;                                // gsum loads in flight together
       for (int c0 = 0; c0 < P.C; c0 += G) {
-        int g[G];
+        if (c0 > 0) {
 #pragma unroll
-        for (int a = 0; a < G; a++) g[a] = c0 + a < P.C ? gsum[(size_t)(c0 + a) * gstride + i] : 0;
+          for (int a = 0; a < G; a++) g[a] = c0 + a < P.C ? gsum[(size_t)(c0 + a) * gstride + i] : 0;
+        }
 #pragma unroll
         for (int a = 0; a < G; a++) {
           if (c0 + a >= P.C) break;
-          const i64 rs = mn_row16_sum((i64)g[a]);
-          if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, rs);
+          if (uni) {
+            const i64 rs = mn_row16_sum((i64)g[a]);
+            if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, rs);
+          } else {
+            mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, (i64)g[a]);
+          }
         }
       }
-      if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 64);
-      const int lo = mn_row16_min(min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w)));
-      const int hi = -mn_row16_min(-max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w)));
-      if ((lane & 15) == 0) mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo, hi);
-    } else if (same) {
-      constexpr int G = 3;                                // gsum loads in flight together
-      for (int c0 = 0; c0 < P.C; c0 += G) {
-        int g[G];
-#pragma unroll
-        for (int a = 0; a < G; a++) g[a] = c0 + a < P.C ? gsum[(size_t)(c0 + a) * gstride + i] : 0;
-#pragma unroll
-        for (int a = 0; a < G; a++)
-          if (c0 + a < P.C) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, (i64)g[a]);
+      const int lo1 = min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w));
+      const int hi1 = max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w));
+      if (uni) {
+        if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 64);
+        const int lo = mn_row16_min(lo1), hi = -mn_row16_min(-hi1);
+        if ((lane & 15) == 0) mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo, hi);
+      } else {
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
+        mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo1, hi1);
       }
-      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
-      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w)),
-                max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w)));
     } else {
-      const int s1 = mn_lds_root_slot(s_root, r.y), s2 = mn_lds_root_slot(s_root, r.z), s3 = mn_lds_root_slot(s_root, r.w);
-      // (the planes are cold again by now: three of them per round trip, not one -- the few waves
-      // that hold such a lane were the whole tail of the kernel, nine HBM latencies long)
-      for (int c0 = 0; c0 < P.C; c0 += 3) {
-        const int c1 = min(c0 + 1, P.C - 1), c2 = min(c0 + 2, P.C - 1);
-        const float4 va = *reinterpret_cast<const float4*>(P.cls + (size_t)c0 * P.N + 4 * (size_t)i);
-        const float4 vb = *reinterpret_cast<const float4*>(P.cls + (size_t)c1 * P.N + 4 * (size_t)i);
-        const float4 vc = *reinterpret_cast<const float4*>(P.cls + (size_t)c2 * P.N + 4 * (size_t)i);
-        mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0, s0, s1, s2, s3, va);
-        if (c0 + 1 < P.C) mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0 + 1, s0, s1, s2, s3, vb);
-        if (c0 + 2 < P.C) mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c0 + 2, s0, s1, s2, s3, vc);
-      }
-      mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 1);
-      mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, P.C, s1, 1);
-      mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, P.C, s2, 1);
-      mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, P.C, s3, 1);
-      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, b.x, b.x);
-      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.y, s1, b.y, b.y);
-      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.z, s2, b.z, b.z);
-      mn_cc_cls(s_min, s_max, clsmin, clsmax, r.w, s3, b.w, b.w);
+      // a lane across a component boundary: queued, and worked off below by ALL lanes of the block,
+      // one (lane, class) item each -- kept inline here it held registers the streaming lanes never
+      // use (76 VGPRs: one block per CU) and its plane reads were nine round trips in a row
+      s_q[atomicAdd(&s_qn, 1)] = i;
     }
   }
+  }
+  const long long dbg_t2 = dbg ? (long long)wall_clock64() : 0;
+  __syncthreads();
+  const long long dbg_t3 = dbg ? (long long)wall_clock64() : 0;
+  {
+    const int nq = s_qn;
+    for (int t = threadIdx.x; t < nq * P.C; t += MN_CC_SUM_THREADS) {
+      const int item = t / P.C, c = t - item * P.C;
+      const int g = s_q[item];
+      int4 r;                                             // (a chase from whatever is visible ends at the root)
+      r.x = mn_cc_root_ro(S.parent, 4 * g); r.y = mn_cc_root_ro(S.parent, 4 * g + 1);
+      r.z = mn_cc_root_ro(S.parent, 4 * g + 2); r.w = mn_cc_root_ro(S.parent, 4 * g + 3);
+      const int s0 = mn_lds_root_slot(s_root, r.x), s1 = mn_lds_root_slot(s_root, r.y);
+      const int s2 = mn_lds_root_slot(s_root, r.z), s3 = mn_lds_root_slot(s_root, r.w);
+      const float4 v = *reinterpret_cast<const float4*>(P.cls + (size_t)c * P.N + 4 * (size_t)g);
+      mn_cc_sums_pixelwise(P, S, s_root, s_val, lp_acc, r, c, s0, s1, s2, s3, v);
+      if (c == 0) {
+        const uchar4 b = *reinterpret_cast<const uchar4*>(cls0 + 4 * (size_t)g);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 1);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.y, P.C, s1, 1);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.z, P.C, s2, 1);
+        mn_cc_add(P, S, s_root, s_val, lp_acc, r.w, P.C, s3, 1);
+        mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, b.x, b.x);
+        mn_cc_cls(s_min, s_max, clsmin, clsmax, r.y, s1, b.y, b.y);
+        mn_cc_cls(s_min, s_max, clsmin, clsmax, r.z, s2, b.z, b.z);
+        mn_cc_cls(s_min, s_max, clsmin, clsmax, r.w, s3, b.w, b.w);
+      }
+    }
+  }
+  if (dbg && threadIdx.x == 0) dbg[6 * (size_t)blockIdx.x + 4] = (long long)wall_clock64();
   __syncthreads();
   if (threadIdx.x < MN_CC_SUM_SLOTS && s_root[threadIdx.x] >= 0) {
     atomicMin(&clsmin[s_root[threadIdx.x]], s_min[threadIdx.x]);
@@ -871,6 +904,10 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     if (v == 0) continue;
     const int slot = j / (P.C + 1), c = j - slot * (P.C + 1);
     mn_cc_add(P, S, s_root, s_val, lp_acc, s_root[slot], c, -1, (i64)v);
+  }
+  if (dbg && threadIdx.x == 0) {
+    long long* d = dbg + 6 * (size_t)blockIdx.x;
+    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = dbg_t3; d[5] = (long long)wall_clock64();
   }
 }
 
