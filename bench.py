@@ -89,8 +89,8 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
@@ -325,6 +325,9 @@ def main():
                       price("mn_cc_sums", avg["ms_cc_sums"], (C + 5) / 4.0,
                             "per-lane class log-products + roots + arg-max classes, C + 5 B/pixel "
                             "(dependent round trips, no roofline claim; on the side stream)")]
+        else:                          # general path (--mode 2/1): class pass + edge pass, SURVEY 8d
+            passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
+                      price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]
         streaming = [p for p in passes if "no roofline claim" not in p["reads"]]
         dom = max(streaming, key=lambda p: p["avg_launch_ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],

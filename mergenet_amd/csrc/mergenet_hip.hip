@@ -574,7 +574,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (fused_cls)
       hipLaunchKernelGGL(mn_cc_sums, dim3((blocks + MN_CC_SUMS_ITERS - 1) / MN_CC_SUMS_ITERS), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
                          (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), (size_t)P.N,
-                         c->lp_acc, clsmin, clsmax, getenv("MN_DBG_SUMS") ? reinterpret_cast<long long*>(c->partial + 8192) : (long long*)nullptr);
+                         c->lp_acc, clsmin, clsmax);
     else
       hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
                          c->lp_acc, clsmin, clsmax);
@@ -992,16 +992,6 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
     else
       rc = MN_ERR_UNPROVEN;
     if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
-  }
-  if (getenv("MN_DBG_SUMS")) {
-    static long long h[6 * 600];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h, c->partial + 8192, sizeof(h), hipMemcpyDeviceToHost);
-    long long t0min = h[0], tend = 0; double a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0; int nb = 256;
-    for (int b = 0; b < nb; b++) { if (h[6*b] < t0min) t0min = h[6*b]; if (h[6*b+5] > tend) tend = h[6*b+5]; }
-    long long lastt0 = 0;
-    for (int b = 0; b < nb; b++) { a1 += h[6*b+1]-h[6*b]; a2 += h[6*b+2]-h[6*b+1]; a3 += h[6*b+3]-h[6*b+2]; a4 += h[6*b+4]-h[6*b+3]; a5 += h[6*b+5]-h[6*b+4]; if (h[6*b]-t0min > lastt0) lastt0 = h[6*b]-t0min; }
-    fprintf(stderr, "sums dbg (10 ns ticks): span %lld, last block start +%lld, avg init %.0f main %.0f wait %.0f queue %.0f flush %.0f\n", tend - t0min, lastt0, a1/nb, a2/nb, a3/nb, a4/nb, a5/nb);
   }
   if (stats) *stats = q.stats;
   q.active = 0;

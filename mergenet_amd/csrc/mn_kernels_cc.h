@@ -786,9 +786,7 @@ __device__ __forceinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const O
 // per-pixel logs.  Leaves parent[] flat.  9 B/pixel read instead of the 36 B/pixel planes.
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ gsum,
-    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax,
-    long long* __restrict__ dbg) {
-  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0;
+    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
   __shared__ int s_root[MN_CC_SUM_SLOTS];
@@ -801,7 +799,6 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
   if (threadIdx.x == 0) s_qn = 0;
   if (threadIdx.x < MN_CC_SUM_SLOTS) { s_root[threadIdx.x] = -1; s_min[threadIdx.x] = 255; s_max[threadIdx.x] = 0; }
   __syncthreads();
-  const long long dbg_t1 = dbg ? (long long)wall_clock64() : 0;
   const int n4 = P.N >> 2;
   // grid-stride: MN_CC_SUMS_ITERS chunks per block, so that the block's table is flushed -- global
   // atomics on the few hot words of the large components -- once per several thousand pixels more
@@ -865,9 +862,7 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     }
   }
   }
-  const long long dbg_t2 = dbg ? (long long)wall_clock64() : 0;
   __syncthreads();
-  const long long dbg_t3 = dbg ? (long long)wall_clock64() : 0;
   {
     const int nq = s_qn;
     for (int t = threadIdx.x; t < nq * P.C; t += MN_CC_SUM_THREADS) {
@@ -893,7 +888,6 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
       }
     }
   }
-  if (dbg && threadIdx.x == 0) dbg[6 * (size_t)blockIdx.x + 4] = (long long)wall_clock64();
   __syncthreads();
   if (threadIdx.x < MN_CC_SUM_SLOTS && s_root[threadIdx.x] >= 0) {
     atomicMin(&clsmin[s_root[threadIdx.x]], s_min[threadIdx.x]);
@@ -904,10 +898,6 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     if (v == 0) continue;
     const int slot = j / (P.C + 1), c = j - slot * (P.C + 1);
     mn_cc_add(P, S, s_root, s_val, lp_acc, s_root[slot], c, -1, (i64)v);
-  }
-  if (dbg && threadIdx.x == 0) {
-    long long* d = dbg + 6 * (size_t)blockIdx.x;
-    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = dbg_t3; d[5] = (long long)wall_clock64();
   }
 }
 

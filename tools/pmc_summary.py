@@ -15,7 +15,7 @@ def per_kernel(path, counter):
         for row in csv.DictReader(fh):
             if row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             if name.startswith("mn_"):
                 acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
@@ -32,10 +32,9 @@ for k in sorted(fetch):
     out["kernels"][k] = {"launches": nf[k], "FETCH_SIZE_kib": round(fetch[k], 1),
                          "WRITE_SIZE_kib": round(write.get(k, 0.0), 1), "hbm_bytes_corrected": hbm}
     out["hbm_bytes_per_launch"][k] = hbm
-grp = ["mn_cc_tiles", "mn_cc_borders", "mn_cc_hook", "mn_cc_flatten"]
-calls = {"mn_cc_tiles": 1, "mn_cc_borders": 1, "mn_cc_hook": 1, "mn_cc_flatten": 2}   # launches per image
+grp = ["mn_cc_tiles", "mn_cc_borders", "mn_cc_flatten", "mn_cc_hook"]      # one launch each per image
 if all(g in out["hbm_bytes_per_launch"] for g in grp):
-    out["hbm_bytes_per_launch"]["mn_cc_tiles+mn_cc_borders+mn_cc_hook+mn_cc_flatten"] = sum(
-        out["hbm_bytes_per_launch"][g] * calls[g] for g in grp)
+    out["hbm_bytes_per_launch"]["mn_cc_tiles+mn_cc_borders+mn_cc_flatten+mn_cc_hook"] = sum(
+        out["hbm_bytes_per_launch"][g] for g in grp)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["hbm_bytes_per_launch"], indent=1))
