@@ -325,7 +325,10 @@ def main():
                       price("mn_cc_sums", avg["ms_cc_sums"], (C + 5) / 4.0,
                             "per-lane class log-products + roots + arg-max classes, C + 5 B/pixel "
                             "(dependent round trips, no roofline claim; on the side stream)")]
-        else:                          # general path (--mode 2/1): class pass + edge pass, SURVEY 8d
+        elif avg["ms_class_pass"] == 0:   # general path starting from the cores: the same single sweep
+            passes = [price("mn_cc_sign", avg["ms_edge_pass"], C + O,
+                            "C class planes + O sameness planes (the only read of the input tensors)")]
+        else:                          # general path on the pixel graph: class pass + edge pass, SURVEY 8d
             passes = [price("mn_class_pass", avg["ms_class_pass"], C, "C class planes"),
                       price("mn_edge_pass_fast", avg["ms_edge_pass"], O, "O sameness planes")]
         streaming = [p for p in passes if "no roofline claim" not in p["reads"]]

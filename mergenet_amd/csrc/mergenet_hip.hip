@@ -61,6 +61,7 @@ struct mn_context {
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready, tail_lds_ready;
   int* wire_counts;       // block counts + total of mn_pack_runs_device (apart from the image's own scratch)
+  int cores_used;         // the last attempt ran the general rounds from the cores (mn_core_clean)
   int cc_clean;           // 1: counters and the speculative record table were cleared at the end of the last image
   HashTab T;
   // output / scratch
@@ -478,7 +479,7 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
 // and the verdict is read by the caller at the end.
 template <int PX>
 static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
-                         u64* neg_list, unsigned sub_cap, bool cls = false) {
+                         u64* neg_list, unsigned sub_cap, bool cls = false, const unsigned* hook_bits = nullptr) {
   const int N = P.N, ngroups = (N + PX - 1) / PX;
   if (!hook) {
     const dim3 g(grid_for(ngroups, MN_CC_SIGN_THREADS)), b(MN_CC_SIGN_THREADS);
@@ -497,12 +498,13 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
 #undef MN_LAUNCH_SIGN
   } else {
     const dim3 gx(8 * ((grid_for(ngroups, 256) + 7) / 8));
-    hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kmask);
+    hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, hook_bits ? hook_bits : (const unsigned*)c->cc_bits,
+                       c->parent, kmask);
   }
 }
 
 static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bool wait, bool with_ball,
-                          bool with_compact, bool fork_before_sums) {
+                          bool with_compact, bool fork_before_sums, bool cores = false) {
   const int N = P.N;
   ObjState S = obj_state(c);
   const dim3 b(256);
@@ -531,21 +533,34 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
   if (!few_events) MN_HIP(hipEventRecord(c->ev[10], st));
+  // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
+  const unsigned* lbits = c->cc_bits;
+  if (cores) {
+    if (!fused_cls) {                // (the class sweep of this form comes after the labelling)
+      const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256);
+      hipLaunchKernelGGL(mn_class_pass, dim3(blocks), dim3(256), 0, st, P, c->cls0);
+    }
+    unsigned* bits2 = reinterpret_cast<unsigned*>(c->label);      // free until the finisher
+    hipLaunchKernelGGL(mn_core_clean, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned*)c->cc_bits,
+                       (const unsigned char*)c->cls0, c->pruned);
+    hipLaunchKernelGGL(mn_core_bits, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned char*)c->pruned, bits2);
+    lbits = bits2;
+  }
   // (labelling the tiles inside the sign sweep -- a block = a 16 x 64 tile -- was tried: 40.6 us for
   // the fused kernel against 27 + 15 apart; the LDS union-find and its barriers sit on every block's
   // critical path and the tile layout reads 256-byte row segments)
-  hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv,
+  hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, lbits, c->parent, kh, kv, dv,
                      c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
   if (kh >= 0 || kv >= 0) {
-    hipLaunchKernelGGL(mn_cc_borders, tiles, dim3(128), 0, st, P, (const unsigned*)c->cc_bits, c->parent, kh, kv, dv);
+    hipLaunchKernelGGL(mn_cc_borders, tiles, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv);
     if (kh >= 0) kmask &= ~(1u << kh);
     if (kv >= 0) kmask &= ~(1u << kv);
   }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
   if (kmask) {
-    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap);
-    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap);
+    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits);
+    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits);
   }
   // the violation counters, the table and (if asked for) the best-record slots were cleared by the
   // caller's fill
@@ -580,6 +595,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
                          c->lp_acc, clsmin, clsmax);
   }
   if (!few_events) MN_HIP(hipEventRecord(c->ev[8], st));
+  if (!cores)                      // (the rounds build their records from the pixel graph: positive ones too)
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
                      (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
                      c->scalars + 6, c->cc_tcount);
@@ -646,7 +662,10 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->merges = merges;
     stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
     float ms = 0;
-    const bool cmode = mode == MN_MODE_COMPONENTS;     // (no separate scoring phase: ev[1], ev[2] not recorded)
+    const bool cmode = mode == MN_MODE_COMPONENTS || c->cores_used;   // (no separate scoring phase: ev[1], ev[2] not recorded)
+    if (c->cores_used && !(opts->debug_flags & 2)) {
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[10]); stats->ms_edge_pass = ms;    // the sweep: class + sameness planes
+    }
     if (!cmode) {
       (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_class_pass = ms;
       (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
@@ -707,6 +726,13 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;
   ObjState S = obj_state(c);
+  // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
+  // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph
+  const bool cores_ok = N <= (1 << 26) && opts->object_merge_factor >= 1e-20f &&
+                        (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
+                                                              : opts->merge_logprob_bias == 0.0f) &&
+                        !(opts->debug_flags & 4);
+  c->cores_used = 0;
 
   bool fused_tail = false;         // the speculative attempt of the C++ variant ends in mn_cc_tail
   FillList fills;
@@ -747,16 +773,25 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   c->cc_clean = 0;                 // (set again only when this attempt has queued its own clean-up)
 
   // ---------------- phase A ----------------
-  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS, &fills, mode == MN_MODE_COMPONENTS);
+  bool cores = mode == MN_MODE_ROUNDS && cores_ok;
+  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS && !cores, &fills, mode == MN_MODE_COMPONENTS || cores);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
     rc = run_components(c, P, st, !speculate, !speculate, !fused_tail, fused_tail);
     if (rc < 0) return rc;
     if (rc == 1) {                 // not sign-separable: start over with the general rounds
       mode = MN_MODE_ROUNDS;
-      rc = run_phase_a(c, P, st, true);
+      cores = cores_ok;
+      FillList none;
+      rc = run_phase_a(c, P, st, !cores, &none, cores);
       if (rc != MN_OK) return rc;
     }
+  }
+  if (cores) {
+    // sweep + labelling of the cores + their class sums and object state; nothing is waited for
+    rc = run_components(c, P, st, false, false, false, false, true);
+    if (rc < 0) return rc;
+    c->cores_used = 1;
   }
 
   // ---------------- phase B ----------------
@@ -764,7 +799,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   int rounds = 0;
   RecList cur = c->LA, nxt = c->LB;
   int R = 0;
-  if (mode == MN_MODE_ROUNDS) {
+  if (mode == MN_MODE_ROUNDS && cores) {
+    rounds = 1;                    // (the contraction stands for round 0)
+  } else if (mode == MN_MODE_ROUNDS) {
     // round 0 on the implicit pixel graph: matching sub-rounds, then one apply
     MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
     hipLaunchKernelGGL(mn_pix_match, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
@@ -857,7 +894,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                          (const int*)(c->scalars + 6), finish_limit,
                          (mode == MN_MODE_COMPONENTS && rounds == 0) ? c->cc_lcount : (int*)nullptr);
     } else {
-      if (mode == MN_MODE_COMPONENTS)   // (the class range of the contraction lived there)
+      if (mode == MN_MODE_COMPONENTS || cores)   // (the class range of the contraction lived there)
         MN_HIP(hipMemsetAsync(c->mapbuf, 0xFF, (size_t)N * sizeof(int), st));
       hipLaunchKernelGGL(mn_finisher, dim3(1), dim3(MN_FIN_THREADS), 0, st, P, S, cur, R, c->mapbuf,
                          c->touched_list, c->cnt, max_steps);
