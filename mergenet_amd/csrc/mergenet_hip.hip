@@ -70,6 +70,8 @@ struct mn_context {
   Counters* cnt;          // device
   int* scalars;           // device: [0] violations, [1] total instances, [2] n_objects
   unsigned* gmax;         // device [64]: highest visible priority of the round
+  unsigned* touch;        // device [64]: records of the round with a matched object at an end (mn_rec_apply)
+  unsigned* h_touch;      // pinned mirror
   float* theta;           // device [1]: band threshold of the round
   int* progress;          // device [MN_MAX_SUBROUNDS]: did sub-round s pair anything
   u64* bg_key;            // device
@@ -217,6 +219,8 @@ static int ctx_alloc(mn_context* c) {
     c->h_lp = reinterpret_cast<double*>(c->h_statblk + o_lp);
   }
   MN_HIP(dev_alloc(c, &c->gmax, 64));
+  MN_HIP(dev_alloc(c, &c->touch, 64));
+  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_touch), 64 * sizeof(unsigned)));
   MN_HIP(dev_alloc(c, &c->theta, 4));
   MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
@@ -261,10 +265,11 @@ extern "C" void mn_destroy(mn_context* c) {
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
                  c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist, c->T.key,
                  c->T.S, c->T.st, c->T.touched, c->block_count, c->wire_counts, c->partial, c->statblk,
-                 c->bg_key, c->gmax, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
+                 c->bg_key, c->gmax, c->touch, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
+  if (c->h_touch) (void)hipHostFree(c->h_touch);
   for (int i = 0; i < 12; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -452,21 +457,28 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   ObjState S = obj_state(c);
   HashTab T = c->T;
   T.mask = (unsigned)(cap - 1);
-  MN_HIP(hipMemsetAsync(T.key, 0xFF, cap * sizeof(u64), st));
-  MN_HIP(hipMemsetAsync(T.S, 0, cap * sizeof(i64), st));
-  MN_HIP(hipMemsetAsync(T.touched, 0, cap, st));
   // the next list is appended to by both kernels below; they also fill the best-record slots and
-  // the band maximum of the coming round
-  MN_HIP(hipMemsetAsync(&c->cnt->n_records, 0, sizeof(int), st));
-  MN_HIP(hipMemsetAsync(c->ball, 0, (size_t)P.N * sizeof(u64), st));
-  MN_HIP(hipMemsetAsync(c->gmax, 0, 64 * sizeof(unsigned), st));
+  // the band maximum of the coming round.  ONE launch clears all of it (six memsets cost six
+  // dispatch gaps, which is what a late round is made of)
+  FillList f;
+  f.add(T.key, cap * sizeof(u64), 0xFF);
+  f.add(T.S, cap * sizeof(i64), 0);
+  f.add(T.touched, cap, 0);
+  f.add(&c->cnt->n_records, sizeof(int), 0);
+  f.add(c->ball, (size_t)P.N * sizeof(u64), 0);
+  f.add(c->gmax, 64 * sizeof(unsigned), 0);
+  f.launch(st);
   if (from_pixels)
     hipLaunchKernelGGL(mn_build_from_pixels, dim3(grid_for(P.N, 256)), dim3(256), 0, st, P, S, T);
   else
     hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, MN_REBUILD_ITEMS)), dim3(256), 0, st, S, src,
                        Rsrc, (const unsigned char*)c->matched, T, L, c->ball, c->gmax, c->cnt);
-  hipLaunchKernelGGL(mn_compact, dim3(grid_for(cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S, T, L,
-                     c->ball, c->gmax, c->cnt);
+  if (cap <= (1u << 16))
+    hipLaunchKernelGGL(mn_compact<1>, dim3(grid_for(cap, 256)), dim3(256), 0, st, P, S, T, L,
+                       c->ball, c->gmax, c->cnt, (const int*)nullptr, (int*)nullptr);
+  else
+    hipLaunchKernelGGL(mn_compact<4>, dim3(grid_for(cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S, T, L,
+                       c->ball, c->gmax, c->cnt, (const int*)nullptr, (int*)nullptr);
   MN_HIP(hipGetLastError());
   if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
   *Rout = c->h_cnt->n_records;
@@ -608,7 +620,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
                      (const int*)clsmin, (const int*)clsmax, c->mate, c->cc_roots, c->scalars + 8,
                      c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
   if (with_compact)                // (mn_cc_tail takes the table itself)
-    hipLaunchKernelGGL(mn_compact, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
+    hipLaunchKernelGGL(mn_compact<4>, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
                        T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
                        (const int*)c->cc_tcount, c->cc_lcount);
   MN_HIP(hipGetLastError());
@@ -825,17 +837,24 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     if (rc != MN_OK) return rc;
   }
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
+    bool first_round = true;
     while (!speculate && R > finish_limit && rounds < 5000) {
-      MN_HIP(hipMemsetAsync(c->matched, 0, N, st));
-      MN_HIP(hipMemsetAsync(c->mate, 0xFF, (size_t)N * sizeof(int), st));
-      MN_HIP(hipMemsetAsync(c->cnt, 0, 4 * sizeof(int), st));   // n_records, any_selected, ...
+      {
+        FillList f;                // one launch instead of five memsets
+        f.add(c->matched, N, 0);
+        f.add(c->mate, (size_t)N * sizeof(int), 0xFF);
+        f.add(c->cnt, 4 * sizeof(int), 0);                       // n_records, any_selected, ...
+        f.add(c->progress, MN_MAX_SUBROUNDS * sizeof(int), 0);
+        f.add(c->touch, 64 * sizeof(unsigned), 0);
+        if (first_round) f.add(c->bsub, (size_t)N * sizeof(u64), 0);   // (accept leaves it clean for the next round)
+        f.launch(st);
+        first_round = false;
+      }
       const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
       hipLaunchKernelGGL(mn_band_threshold, dim3(1), dim3(64), 0, st, (const unsigned*)c->gmax,
                          P.bias, P.variant, band_gamma, c->theta);
-      MN_HIP(hipMemsetAsync(c->progress, 0, MN_MAX_SUBROUNDS * sizeof(int), st));
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
                          (const float*)c->theta, c->matched, c->mate, c->progress, c->cnt);
-      MN_HIP(hipMemsetAsync(c->bsub, 0, (size_t)N * sizeof(u64), st));   // accept cleans up after
       // late rounds are launch-bound: fewer matching sub-rounds once the list is small
       const int sub_r = R > (1 << 20) ? subrounds : (subrounds > 8 ? subrounds / 4 : subrounds);
       for (int s = 1; s < sub_r; s++) {
@@ -845,8 +864,17 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
         hipLaunchKernelGGL(mn_obj_accept, go, b, 0, st, N, c->bsub, c->matched, c->mate,
                            c->progress, s, c->cnt);
       }
-      hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const int*)c->mate, c->cnt);
-      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);   // load <= 2/3
+      hipLaunchKernelGGL(mn_rec_apply, g, b, 0, st, P, S, cur, R, (const int*)c->mate, c->cnt, c->touch);
+      // the table only takes the records with a matched object at an end (the others go straight to
+      // the next list): for a big list it is worth a host round trip to size it for those
+      size_t need = (size_t)R;
+      if (R > (1 << 18)) {
+        MN_HIP(hipMemcpyAsync(c->h_touch, c->touch, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        MN_HIP(hipStreamSynchronize(st));
+        need = 0;
+        for (int w = 0; w < 64; w++) need += c->h_touch[w];
+      }
+      size_t cap = next_pow2(need + need / 2 + 1024);   // load <= 2/3
       if (cap > c->cap) cap = c->cap;
       int Rn = 0;
       rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn);

@@ -176,21 +176,25 @@ __global__ __launch_bounds__(256) void mn_build_from_pixels(ImgParams P, ObjStat
 // stale-high), the packed key goes into both endpoints' best slot, the block maximum feeds the
 // band threshold.  A block owns 1024 consecutive slots and reserves its output range with ONE
 // atomic.
+// PER = slots per lane: 4 for the big tables; a table of a few thousand slots is scanned one slot per
+// lane (a lane's slots are scored one after the other, each a chain of dependent loads: with 4 per
+// lane a small table took 45 us of pure latency).
 #define MN_COMPACT_SLOTS 1024
+template <int PER>
 __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashTab T, RecList L,
                                                   u64* __restrict__ ball,
                                                   unsigned* __restrict__ gmax,
                                                   Counters* __restrict__ cnt,
                                                   const int* __restrict__ tcount = nullptr,
                                                   int* __restrict__ lcount = nullptr) {
-  __shared__ int sh_w[4][4];
+  __shared__ int sh_w[PER][4];
   __shared__ int sh_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned base = blockIdx.x * MN_COMPACT_SLOTS;
-  u64 key[4];
-  int before[4];
+  const unsigned base = blockIdx.x * (256 * PER);
+  u64 key[PER];
+  int before[PER];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < PER; j++) {
     const unsigned slot = base + j * 256 + threadIdx.x;
     key[j] = slot <= T.mask ? T.key[slot] : MN_EMPTY;
     const u64 m = __ballot(key[j] != MN_EMPTY);
@@ -200,14 +204,14 @@ __global__ __launch_bounds__(256) void mn_compact(ImgParams P, ObjState S, HashT
   __syncthreads();
   if (threadIdx.x == 0) {
     int tot = 0;
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < PER; j++)
       for (int w = 0; w < 4; w++) { const int t = sh_w[j][w]; sh_w[j][w] = tot; tot += t; }
     sh_base = tot ? atomicAdd(&cnt->n_records, tot) : 0;
   }
   __syncthreads();
   unsigned mybits = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < PER; j++) {
     if (key[j] == MN_EMPTY) continue;
     const unsigned slot = base + j * 256 + threadIdx.x;
     const i64 s = T.S[slot];
@@ -346,13 +350,24 @@ __global__ __launch_bounds__(256) void mn_rec_refresh(ImgParams P, ObjState S, R
 }
 
 // Selected records: refresh (stale-low) or merge (segment.cc:560-565, 602-642).
+// `touch` (64 words): how many records have a matched object at either end -- the only ones the
+// rebuild re-inserts, i.e. what the next table has to hold (one atomic per block, spread over the words)
 __global__ __launch_bounds__(256) void mn_rec_apply(ImgParams P, ObjState S, RecList L, int R,
                                                     const int* __restrict__ mate,
-                                                    Counters* __restrict__ cnt) {
+                                                    Counters* __restrict__ cnt,
+                                                    unsigned* __restrict__ touch) {
+  __shared__ int sh_n;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  const u64 key0 = L.key[i];
-  if (mate[mn_key_u(key0)] != mn_key_v(key0)) return;     // not the record of a matched pair
+  if (threadIdx.x == 0) sh_n = 0;
+  __syncthreads();
+  const u64 key0 = i < R ? L.key[i] : MN_EMPTY;
+  int mu = -1, mv = -1;
+  if (key0 != MN_EMPTY) { mu = mate[mn_key_u(key0)]; mv = mate[mn_key_v(key0)]; }
+  const u64 nz = __ballot(mu >= 0 || mv >= 0);
+  if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&sh_n, __popcll(nz));
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_n) atomicAdd(&touch[blockIdx.x & 63], (unsigned)sh_n);
+  if (key0 == MN_EMPTY || mu != mn_key_v(key0)) return;   // not the record of a matched pair
   cnt->any_selected = 1;
   const float f = L.fr[i], st = L.st[i];
   // csegment merges when the re-scored priority equals the popped one (segment.cc:561); a
