@@ -220,7 +220,7 @@ static int ctx_alloc(mn_context* c) {
   }
   MN_HIP(dev_alloc(c, &c->gmax, 64));
   MN_HIP(dev_alloc(c, &c->touch, 64));
-  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_touch), 64 * sizeof(unsigned)));
+  MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_touch), (64 + MN_MAX_SUBROUNDS) * sizeof(unsigned)));
   MN_HIP(dev_alloc(c, &c->theta, 4));
   MN_HIP(dev_alloc(c, &c->progress, MN_MAX_SUBROUNDS));
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
@@ -555,7 +555,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     unsigned* bits2 = reinterpret_cast<unsigned*>(c->label);      // free until the finisher
     hipLaunchKernelGGL(mn_core_clean, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned*)c->cc_bits,
                        (const unsigned char*)c->cls0, c->pruned);
-    hipLaunchKernelGGL(mn_core_bits, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned char*)c->pruned, bits2);
+    hipLaunchKernelGGL(mn_core_bits, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned char*)c->pruned, bits2,
+                       c->touch);                   // (cleared by the caller's fill)
     lbits = bits2;
   }
   // (labelling the tiles inside the sign sweep -- a block = a 16 x 64 tile -- was tried: 40.6 us for
@@ -601,7 +602,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (fused_cls)
       hipLaunchKernelGGL(mn_cc_sums, dim3((blocks + MN_CC_SUMS_ITERS - 1) / MN_CC_SUMS_ITERS), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
                          (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), (size_t)P.N,
-                         c->lp_acc, clsmin, clsmax);
+                         c->lp_acc, clsmin, clsmax, cores ? (const unsigned char*)c->pruned : (const unsigned char*)nullptr);
     else
       hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
                          c->lp_acc, clsmin, clsmax);
@@ -617,8 +618,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
   hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for((size_t)(N >> 4) > 0 ? (size_t)(N >> 4) : 1, 256)), b, 0, st, P, S,
                      (const unsigned char*)c->matched, (const i64*)c->lp_acc,
-                     (const int*)clsmin, (const int*)clsmax, c->mate, c->cc_roots, c->scalars + 8,
-                     c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
+                     (const int*)clsmin, (const int*)clsmax, c->mate, cores ? (int*)nullptr : c->cc_roots,
+                     c->scalars + 8, c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
   if (with_compact)                // (mn_cc_tail takes the table itself)
     hipLaunchKernelGGL(mn_compact<4>, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
                        T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
@@ -786,6 +787,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
 
   // ---------------- phase A ----------------
   bool cores = mode == MN_MODE_ROUNDS && cores_ok;
+  if (cores_ok) fills.add(c->touch, 64 * sizeof(unsigned), 0);     // (edges outside the cores: mn_core_bits)
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS && !cores, &fills, mode == MN_MODE_COMPONENTS || cores);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
@@ -795,6 +797,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       mode = MN_MODE_ROUNDS;
       cores = cores_ok;
       FillList none;
+      if (cores) none.add(c->touch, 64 * sizeof(unsigned), 0);
       rc = run_phase_a(c, P, st, !cores, &none, cores);
       if (rc != MN_OK) return rc;
     }
@@ -832,12 +835,20 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     // on the device: launches below are sized for the most the finisher takes
     R = speculate ? finish_limit : c->h_cnt->n_records;
   } else {
-    const size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
+    size_t cap0 = next_pow2((size_t)R0 + (size_t)R0 / 4 + 1024);
+    if (cores && R0 > (1 << 18)) {   // only the edges outside the cores become records: worth a round trip
+      MN_HIP(hipMemcpyAsync(c->h_touch, c->touch, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      MN_HIP(hipStreamSynchronize(st));
+      size_t need = 0;
+      for (int w = 0; w < 64; w++) need += c->h_touch[w];
+      cap0 = next_pow2(need + need / 2 + 1024);
+    }
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
   }
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
     bool first_round = true;
+    int productive = subrounds;    // matching sub-rounds of the previous round that paired anything, + 1
     while (!speculate && R > finish_limit && rounds < 5000) {
       {
         FillList f;                // one launch instead of five memsets
@@ -856,7 +867,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       hipLaunchKernelGGL(mn_obj_match_mutual, go, b, 0, st, N, (const u64*)c->ball,
                          (const float*)c->theta, c->matched, c->mate, c->progress, c->cnt);
       // late rounds are launch-bound: fewer matching sub-rounds once the list is small
-      const int sub_r = R > (1 << 20) ? subrounds : (subrounds > 8 ? subrounds / 4 : subrounds);
+      // ... and a sub-round is two launches that return at once when the one before paired nothing:
+      // how far the previous round got (read back with its counters) bounds this one, plus a margin
+      int sub_r = R > (1 << 20) ? subrounds : (subrounds > 8 ? subrounds / 4 : subrounds);
+      if (sub_r > productive + 3) sub_r = productive + 3;
       for (int s = 1; s < sub_r; s++) {
         hipLaunchKernelGGL(mn_obj_propose, go, b, 0, st, N, (const u64*)c->ball,
                            (const float*)c->theta, (const unsigned char*)c->matched, c->bsub,
@@ -877,8 +891,12 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       size_t cap = next_pow2(need + need / 2 + 1024);   // load <= 2/3
       if (cap > c->cap) cap = c->cap;
       int Rn = 0;
+      MN_HIP(hipMemcpyAsync(c->h_touch + 64, c->progress, MN_MAX_SUBROUNDS * sizeof(int), hipMemcpyDeviceToHost, st));
       rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn);
       if (rc != MN_OK) return rc;
+      productive = 1;
+      for (int w = 1; w < sub_r; w++)
+        if (c->h_touch[64 + w]) productive = w + 1;
       rounds++;
       const int selected = c->h_cnt->any_selected;
       RecList t = cur; cur = nxt; nxt = t;

@@ -576,19 +576,32 @@ __global__ __launch_bounds__(256) void mn_core_clean(ImgParams P, const unsigned
 
 // out-edges between two clean pixels, in the format of the sign sweep's masks (a set bit implies an
 // in-bounds neighbour): what the labelling stages run on
+// `outside` (64 words): in-bounds edges that are NOT between two clean pixels -- an upper bound of the
+// records the rounds start with, which sizes their first table
 __global__ __launch_bounds__(256) void mn_core_bits(ImgParams P, const unsigned char* __restrict__ clean,
-                                                    unsigned* __restrict__ bits2) {
+                                                    unsigned* __restrict__ bits2,
+                                                    unsigned* __restrict__ outside) {
+  __shared__ int sh_n;
+  if (threadIdx.x == 0) sh_n = 0;
+  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.N) return;
-  unsigned m = 0u;
-  if (clean[p]) {
+  int out = 0;
+  if (p < P.N) {
+    unsigned m = 0u;
+    const bool mine = clean[p] != 0;
     const int r = p / P.W, c = p - r * P.W;
     for (int k = 0; k < P.O; k++) {
       const int rr = r + P.di[k], cc = c + P.dj[k];
-      if (rr >= 0 && rr < P.H && cc >= 0 && cc < P.W && clean[rr * P.W + cc]) m |= 1u << k;
+      if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
+      if (mine && clean[rr * P.W + cc]) m |= 1u << k;
+      else out++;
     }
+    bits2[p] = m;
   }
-  bits2[p] = m;
+  for (int off = 32; off > 0; off >>= 1) out += __shfl_xor(out, off);
+  if ((threadIdx.x & 63) == 0 && out) atomicAdd(&sh_n, out);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_n) atomicAdd(&outside[blockIdx.x & 63], (unsigned)sh_n);
 }
 
 // Class pass of components mode: one sweep over the C class planes gives every pixel its arg-max
@@ -838,7 +851,10 @@ __device__ __forceinline__ void mn_cc_sums_pixelwise(const ImgParams& P, const O
 // per-pixel logs.  Leaves parent[] flat.  9 B/pixel read instead of the 36 B/pixel planes.
 __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     ImgParams P, ObjState S, const unsigned char* __restrict__ cls0, const int* __restrict__ gsum,
-    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax) {
+    size_t gstride, i64* __restrict__ lp_acc, int* __restrict__ clsmin, int* __restrict__ clsmax,
+    const unsigned char* __restrict__ clean) {
+  // `clean` (cores ahead of the rounds, else null): a pixel that is not clean is a component of its
+  // own by construction -- size 1, class sums read from the planes when needed -- and takes no sums
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   u64* s_val = reinterpret_cast<u64*>(cc_smem);                   // [SLOTS][C+1], index C = count
   __shared__ int s_root[MN_CC_SUM_SLOTS];
@@ -920,6 +936,25 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     for (int t = threadIdx.x; t < nq * P.C; t += MN_CC_SUM_THREADS) {
       const int item = t / P.C, c = t - item * P.C;
       const int g = s_q[item];
+      if (clean) {
+        const uchar4 cl = *reinterpret_cast<const uchar4*>(clean + 4 * (size_t)g);
+        const unsigned char clj[4] = {cl.x, cl.y, cl.z, cl.w};
+        const uchar4 bq = *reinterpret_cast<const uchar4*>(cls0 + 4 * (size_t)g);
+        const unsigned char bj[4] = {bq.x, bq.y, bq.z, bq.w};
+        for (int j = 0; j < 4; j++) {
+          const int px = 4 * g + j;
+          if (!clj[j]) { if (c == 0) S.osize[px] = 1; continue; }
+          const int rt = mn_cc_root_ro(S.parent, px);
+          const int sl = mn_lds_root_slot(s_root, rt);
+          const float v = mn_ld_class(P, c, px);
+          mn_cc_add(P, S, s_root, s_val, lp_acc, rt, c, sl, (i64)__float2int_rn(logf(v) * (float)MN_LP_FIX));
+          if (c == 0) {
+            mn_cc_add(P, S, s_root, s_val, lp_acc, rt, P.C, sl, 1);
+            mn_cc_cls(s_min, s_max, clsmin, clsmax, rt, sl, bj[j], bj[j]);
+          }
+        }
+        continue;
+      }
       int4 r;                                             // (a chase from whatever is visible ends at the root)
       r.x = mn_cc_root_ro(S.parent, 4 * g); r.y = mn_cc_root_ro(S.parent, 4 * g + 1);
       r.z = mn_cc_root_ro(S.parent, 4 * g + 2); r.w = mn_cc_root_ro(S.parent, 4 * g + 3);
@@ -1074,9 +1109,11 @@ __device__ __forceinline__ void mn_cc_finish_root(const ImgParams& P, const ObjS
                                                   int* __restrict__ compsize, int* __restrict__ rootlist,
                                                   int* __restrict__ nroots, int* __restrict__ violations) {
   if (S.parent[p] != p) return;
-  rootlist[atomicAdd(nroots, 1)] = p;     // (component roots are few)
-  compsize[p] = S.osize[p];               // kept for the certificate: osize grows in the merge
-  if (clsmin[p] != clsmax[p]) atomicAdd(violations, 1);                // (c) one class per component
+  if (rootlist) {                         // (null: cores ahead of the rounds -- no certificate from the contraction)
+    rootlist[atomicAdd(nroots, 1)] = p;     // (component roots are few)
+    compsize[p] = S.osize[p];               // kept for the certificate: osize grows in the merge
+    if (clsmin[p] != clsmax[p]) atomicAdd(violations, 1);                // (c) one class per component
+  }
   if (S.osize[p] <= 1) return;            // a lone pixel keeps reading its class planes
   for (int c = 0; c < P.C; c++)
     S.lpsum[(size_t)c * P.N + p] = (float)((double)lp_acc[(size_t)c * P.N + p] * (1.0 / MN_LP_FIX));
