@@ -19,6 +19,7 @@
 #include "mn_kernels_prepare.h"
 #include "mn_kernels_cc.h"
 #include "mn_kernels_tail.h"
+#include "mn_kernels_oc.h"
 
 // Counters | 16 int scalars | 4 doubles, each part 16-byte aligned
 // scalars: [0] edge violations [1] instances [2] objects [3] class violations [4] record violations
@@ -453,7 +454,7 @@ static int read_counters(mn_context* c, hipStream_t st) {
 }
 
 static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t cap, RecList L,
-                      bool from_pixels, RecList src, int Rsrc, int* Rout) {
+                      bool from_pixels, RecList src, int Rsrc, int* Rout, bool fresh_all = false) {
   ObjState S = obj_state(c);
   HashTab T = c->T;
   T.mask = (unsigned)(cap - 1);
@@ -472,7 +473,7 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
     hipLaunchKernelGGL(mn_build_from_pixels, dim3(grid_for(P.N, 256)), dim3(256), 0, st, P, S, T);
   else
     hipLaunchKernelGGL(mn_rebuild, dim3(grid_for(Rsrc, MN_REBUILD_ITEMS)), dim3(256), 0, st, S, src,
-                       Rsrc, (const unsigned char*)c->matched, T, L, c->ball, c->gmax, c->cnt);
+                       Rsrc, (const unsigned char*)c->matched, T, L, c->ball, c->gmax, c->cnt, fresh_all ? 1 : 0);
   if (cap <= (1u << 16))
     hipLaunchKernelGGL(mn_compact<1>, dim3(grid_for(cap, 256)), dim3(256), 0, st, P, S, T, L,
                        c->ball, c->gmax, c->cnt, (const int*)nullptr, (int*)nullptr);
@@ -482,6 +483,39 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   MN_HIP(hipGetLastError());
   if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
   *Rout = c->h_cnt->n_records;
+  return MN_OK;
+}
+
+// Contraction of the order-free clusters of objects of a record list (mn_kernels_oc.h): object
+// state updated, members marked in matched[]; the caller rebuilds the list if `merged` comes back set.
+static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, RecList L, int R,
+                             i64 tau, bool* merged) {
+  ObjState S = obj_state(c);
+  int* up = c->root;                    // free between the cores and the output stage
+  unsigned char* bad = c->pruned;
+  const int N = P.N;
+  FillList f;
+  f.add(c->matched, (size_t)N, 0);
+  f.add(&c->cnt->any_selected, sizeof(int), 0);
+  f.launch(st);
+  const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
+  hipLaunchKernelGGL(mn_oc_init, go, b, 0, st, N, (const int*)c->parent, up, bad);
+  if (R > (1 << 16)) {                  // a sample first, then everything against flat labels
+    hipLaunchKernelGGL(mn_oc_link, dim3(grid_for((R + 7) / 8, 256)), b, 0, st, S, L, R, tau, up, 8);
+    hipLaunchKernelGGL(mn_oc_flatten, go, b, 0, st, N, (const int*)c->parent, up);
+  }
+  hipLaunchKernelGGL(mn_oc_link, g, b, 0, st, S, L, R, tau, up, 1);
+  hipLaunchKernelGGL(mn_oc_flatten, go, b, 0, st, N, (const int*)c->parent, up);
+  hipLaunchKernelGGL(mn_oc_check, g, b, 0, st, S, L, R, tau, (const int*)up, bad);
+  hipLaunchKernelGGL(mn_oc_clear, go, b, 0, st, P, (const int*)c->parent, (const int*)up,
+                     (const unsigned char*)bad, c->lp_acc);
+  const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
+  hipLaunchKernelGGL(mn_oc_gather, dim3(grid_for(N, MN_OC_THREADS)), dim3(MN_OC_THREADS), lds, st, P, S,
+                     (const int*)up, (const unsigned char*)bad, c->lp_acc, c->matched, c->cnt);
+  hipLaunchKernelGGL(mn_oc_finish, go, b, 0, st, P, S, (const i64*)c->lp_acc, (const unsigned char*)c->matched);
+  MN_HIP(hipGetLastError());
+  if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
+  *merged = c->h_cnt->any_selected != 0;
   return MN_OK;
 }
 
@@ -846,6 +880,30 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
   }
+  // log-odds margin of the contraction arguments in the fixed-point unit of the sums (fill_params)
+  i64 tau_fixed = 1;
+  if (cores_ok) {
+    const double n = (double)N;
+    const double ulp = (double)nextafterf(P.bias, INFINITY) - (double)P.bias;
+    const double tau = fmax(2.0 * n * ulp, 1e-30 * n * n) / (double)P.omf;
+    tau_fixed = (i64)ceil(tau * MN_FIX_ONE) + 1;
+  }
+  const bool clusters = mode == MN_MODE_ROUNDS && cores_ok && !(opts->debug_flags & 8);
+  if (clusters && R > 0) {
+    // order-free clusters of the initial objects (on a sign-separable map: everything)
+    bool merged = false;
+    rc = contract_clusters(c, P, st, cur, R, tau_fixed, &merged);
+    if (rc != MN_OK) return rc;
+    if (merged) {
+      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);
+      if (cap > c->cap) cap = c->cap;
+      int Rn = 0;
+      rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn, true);
+      if (rc != MN_OK) return rc;
+      RecList t = cur; cur = nxt; nxt = t;
+      R = Rn;
+    }
+  }
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
     bool first_round = true;
     int productive = subrounds;    // matching sub-rounds of the previous round that paired anything, + 1
@@ -902,6 +960,23 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       RecList t = cur; cur = nxt; nxt = t;
       R = Rn;
       if (selected == 0) break;     // nothing visible any more: the queue is empty
+    }
+  }
+  if (clusters && rounds > 1 && R > 0) {
+    // hand-over: all records fresh (as the sequential phase always started), then the clusters the
+    // rounds have made order-free go in one step instead of one finisher step per fragment
+    hipLaunchKernelGGL(mn_rec_refresh, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R);
+    bool merged = false;
+    rc = contract_clusters(c, P, st, cur, R, tau_fixed, &merged);
+    if (rc != MN_OK) return rc;
+    if (merged) {
+      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);
+      if (cap > c->cap) cap = c->cap;
+      int Rn = 0;
+      rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn, true);
+      if (rc != MN_OK) return rc;
+      RecList t = cur; cur = nxt; nxt = t;
+      R = Rn;
     }
   }
   const bool want_cert = opts->compute_logprob != 0;

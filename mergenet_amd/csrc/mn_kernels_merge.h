@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void mn_rebuild(ObjState S, RecList L, int R,
                                                   const unsigned char* __restrict__ matched,
                                                   HashTab T, RecList Out, u64* __restrict__ ball,
                                                   unsigned* __restrict__ gmax,
-                                                  Counters* __restrict__ cnt) {
+                                                  Counters* __restrict__ cnt, int fresh_all) {
   __shared__ int sh_w[4][4];
   __shared__ int sh_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void mn_rebuild(ObjState S, RecList L, int R,
         const int nu = S.parent[u], nv = S.parent[v];
         if (nu != nv) {
           const unsigned slot = mn_tab_insert(T, mn_key(nu, nv), L.S[i]);
-          if (nu != u || nv != v) T.touched[slot] = 1;   // incident to an absorbed object: re-score
+          // (fresh_all: after a cluster contraction every record of a contracted object is scored
+          //  anew, as components mode scores the records between its components)
+          if (nu != u || nv != v || fresh_all) T.touched[slot] = 1;   // incident to an absorbed object: re-score
           else T.st[slot] = L.st[i];                     // keeps its stored priority
         }
       }
