@@ -6,7 +6,11 @@ import torch
 from mergenet_amd import synth, segmenter as seg
 H, W = 1024, 2048
 offs = synth.generate_offsets(40, 10)
-s = synth.synth_v1(H, W, 9, offs, 1000)
+# MN_PROF_BLUR=1: a network-like map (certainty fades at the boundaries: not sign-separable)
+if os.environ.get('MN_PROF_BLUR') == '1':
+    s = synth.blurred_v1(H, W, 9, offs, 4242, radius=2, noise=0.05)
+else:
+    s = synth.synth_v1(H, W, 9, offs, 1000)
 m = seg.Merger(H, W, 9, len(offs))
 cp = torch.from_numpy(s.class_probs).cuda(); sp = torch.from_numpy(s.sameness_probs).cuda()
 # a 1 GiB scratch write between launches evicts the 256 MiB Infinity Cache so each image reads HBM
@@ -18,4 +22,5 @@ for it in range(n):
     torch.cuda.synchronize()
     _, _, _, st = m.segment(cp, sp, offs, seg.default_options(mode=int(os.environ.get('MN_PROF_MODE', '0'))))
     tot += st["ms_total"]
-print("mode_used %d, avg device time %.3f ms per image (cold caches)" % (st["mode_used"], tot / n))
+print("mode_used %d, avg device time %.3f ms per image (cold caches), rounds %d, finisher steps %d, instances %d" % (
+    st["mode_used"], tot / n, st["rounds"], st["finisher_steps"], st["num_instances"]))
