@@ -563,6 +563,10 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (kv < 0 && P.dj[k] == 0 && (P.di[k] == 1 || P.di[k] == -1)) { kv = k; dv = P.di[k]; }
   }
   const bool few_events = (c->debug_flags & 2) != 0;   // no per-kernel timestamps on the caller's stream
+  // bit 4: only the sweep is timed (ev[0], ev[10]).  An event costs the host ~3.5 us to record and ~8 us
+  // to read (hipEventElapsedTime): a dozen of them per image made the HOST the bottleneck of a loop
+  // over images (0.18 ms per step against 0.12 ms of kernels on the caller's stream).
+  const bool lean = (c->debug_flags & 16) != 0;
   // negative-edge list: one region per block of the sign sweep, able to hold every edge of the block
   u64* neg_list = c->cc_neglist;
   const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
@@ -622,7 +626,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     st = c->side;
   }
-  if (!few_events) MN_HIP(hipEventRecord(c->ev[7], st));
+  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[7], st));
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
     if (lds > c->cc_sum_lds) {
@@ -641,12 +645,12 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
       hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
                          c->lp_acc, clsmin, clsmax);
   }
-  if (!few_events) MN_HIP(hipEventRecord(c->ev[8], st));
+  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[8], st));
   if (!cores)                      // (the rounds build their records from the pixel graph: positive ones too)
   hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
                      (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
                      c->scalars + 6, c->cc_tcount);
-  MN_HIP(hipEventRecord(c->ev[9], st));
+  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[9], st));
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
   // input turns out not to be separable, all of it is discarded (run_phase_a starts over).
@@ -718,14 +722,20 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
       (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_edge_pass = ms;
     }
     stats->ms_score = stats->ms_class_pass + stats->ms_edge_pass;
-    (void)hipEventElapsedTime(&ms, c->ev[cmode ? 0 : 2], c->ev[3]); stats->ms_merge = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+    const bool lean = (opts->debug_flags & 16) != 0 && speculate && mode == MN_MODE_COMPONENTS &&
+                      opts->variant == MN_VARIANT_CSEGMENT;      // (only ev[0], ev[10] were recorded)
+    if (!lean) {
+      (void)hipEventElapsedTime(&ms, c->ev[cmode ? 0 : 2], c->ev[3]); stats->ms_merge = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); stats->ms_output = ms;
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); stats->ms_total = ms;
+    }
     if (mode == MN_MODE_COMPONENTS && !(opts->debug_flags & 2)) {
       (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[10]); stats->ms_cc_edges = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[10], c->ev[7]); stats->ms_cc_label = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
-      (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_cross = ms;
+      if (!(opts->debug_flags & 16)) {
+        (void)hipEventElapsedTime(&ms, c->ev[10], c->ev[7]); stats->ms_cc_label = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_cross = ms;
+      }
     }
   }
   g_last_status = rc;
@@ -821,7 +831,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
 
   // ---------------- phase A ----------------
   bool cores = mode == MN_MODE_ROUNDS && cores_ok;
-  if (cores_ok) fills.add(c->touch, 64 * sizeof(unsigned), 0);     // (edges outside the cores: mn_core_bits)
+  if (cores) fills.add(c->touch, 64 * sizeof(unsigned), 0);        // (edges outside the cores: mn_core_bits)
   rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS && !cores, &fills, mode == MN_MODE_COMPONENTS || cores);
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
@@ -1021,7 +1031,8 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                          c->touched_list, c->cnt, max_steps);
     }
   }
-  MN_HIP(hipEventRecord(c->ev[3], st));
+  const bool lean = (opts->debug_flags & 16) != 0 && fused_tail;   // (only the sweep is timed)
+  if (!lean) MN_HIP(hipEventRecord(c->ev[3], st));
 
   // ---------------- output ----------------
   const unsigned char* pruned = NULL;
@@ -1073,7 +1084,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
                          c->scalars, speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr);
   }
-  MN_HIP(hipEventRecord(c->ev[4], st));
+  if (!lean) MN_HIP(hipEventRecord(c->ev[4], st));
   MN_HIP(hipGetLastError());
   c->last_params = P;
   c->last_valid = 1;

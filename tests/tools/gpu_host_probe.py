@@ -1,0 +1,31 @@
+"""Where the host's time goes in the bench loop (GPU box): launch vs read-back, with and without the
+per-kernel events."""
+import sys, time
+sys.path.insert(0, '.')
+import torch
+from collections import deque
+from mergenet_amd import synth, segmenter as seg
+H, W, C = 1024, 2048, 9
+offs = synth.generate_offsets(40, 10)
+imgs = []
+for sd in (1000, 1001, 1002, 1003):
+    s = synth.synth_v1(H, W, C, offs, sd)
+    imgs.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
+for nctx in (4, 6):
+    ring_m = [seg.Merger(H, W, C, len(offs)) for _ in range(nctx)]
+    for flags in (0, 2):
+        opts = seg.default_options(merge_logprob_bias=0.03, debug_flags=flags)
+        for rep in range(2):
+            ring = deque(); tl = tr = 0.0
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n = 1000
+            for i in range(n):
+                a = time.perf_counter()
+                ring.append(ring_m[i % nctx].segment_async(*imgs[i % 4], offs, opts))
+                b = time.perf_counter(); tl += b - a
+                if len(ring) >= nctx:
+                    ring.popleft().result()
+                    tr += time.perf_counter() - b
+            while ring: ring.popleft().result()
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("contexts %d flags %d: %.1f us/step; host in launch %.1f us, in read-back %.1f us" % (nctx, flags, dt / n * 1e6, tl / n * 1e6, tr / n * 1e6), flush=True)
