@@ -77,11 +77,18 @@ typedef struct mn_options {
                                   the certificate; 0: skip both (total_logprob NaN, certified 0)  */
   int no_handover_refresh;     /* ROUNDS: 1 = keep stored priorities when the finisher takes over  */
   int band_permille;           /* ROUNDS: a round merges only records whose gain is >= this many
-                                  thousandths of the round's best gain (0 = default 100, <0 = off;
-                                  parity with the reference was lost at 10, once in 65 runs at 25, never from 50 up)   */
+                                  thousandths of the round's best gain (0 = default 50, <0 = off;
+                                  round 1, rounds from single pixels: parity with the reference lost at
+                                  10, once in 65 runs at 25, never from 50 up; round 2, rounds from the
+                                  cores: 100, 50 and 20 give the same verdict and pixel agreement on
+                                  every reference vector, 50 is a fifth faster than 100)            */
   int debug_flags;             /* bit 0: use the generic edge pass where the fast form would run (tests
                                   compare the two); bit 1: no per-kernel timestamps in components mode
-                                  (ms_cc_* stay 0; each is an event on the caller's stream)        */
+                                  (ms_cc_* stay 0; each is an event on the caller's stream); bit 2:
+                                  general rounds from single pixels instead of from the cores; bit 3: no
+                                  contraction of order-free clusters in the general rounds; bit 4: only
+                                  the sweep is timed (ms_cc_edges; the other ms_* stay 0) -- an event
+                                  costs the host ~3.5 us to record and ~8 us to read               */
   int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
                                   order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
                                   has at most exact_limit_proof initial records, else the call returns

@@ -769,7 +769,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
   if (subrounds > MN_MAX_SUBROUNDS) subrounds = MN_MAX_SUBROUNDS;
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
-                                                   : (opts->band_permille < 0 ? 0.0f : 0.1f);
+                                                   : (opts->band_permille < 0 ? 0.0f : 0.05f);
   int mode = force_mode > 0 ? force_mode : opts->mode;
   if (mode != MN_MODE_EXACT && mode != MN_MODE_ROUNDS && mode != MN_MODE_COMPONENTS)
     mode = (R0 <= exact_limit) ? MN_MODE_EXACT : MN_MODE_COMPONENTS;

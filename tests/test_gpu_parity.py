@@ -108,6 +108,25 @@ def test_crowded_48_seed_6408_rounds_known_gap(oracle):
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
 
 
+@pytest.mark.parametrize("name", ["cseg_synth_1024x2048_cfg2", "cseg_synth_1024x2048_s1003", "cseg_synth_512x1024_s1001",
+                                  "cseg_synth_400x667_c81", "cseg_crowd48_256x512_s6400", "cseg_crowd48_256x512_s6408"])
+def test_rounds_without_cluster_contraction_equal_reference(oracle, name):
+    """The parallel rounds themselves (from the cores; order-free clusters NOT contracted, debug_flags
+    bit 3, so that the rounds really run on these separable maps) equal the reference's result."""
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=8)
+    assert stats["rounds"] > 3
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
+@pytest.mark.parametrize("name", ["cseg_synth_512x1024_s1000", "cseg_synth_256x512"])
+def test_rounds_from_single_pixels_equal_reference(oracle, name):
+    """... and so do the rounds of round 1 (no cores, no clusters: debug_flags bits 2 and 3)."""
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=12)
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
+
+
 def test_golden_csegment_256x512_rounds(oracle):
     g = gu.load("cseg_synth_256x512")
     mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS)
