@@ -98,9 +98,12 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
-    ap.add_argument("--contexts", type=int, default=4,
+    ap.add_argument("--contexts", type=int, default=3,
                     help="merger contexts in rotation on the one compute stream (launch of image i precedes the "
                          "read-back of image i - contexts + 1)")
+    ap.add_argument("--replay", action="store_true",
+                    help="fixed output buffers per context + hipGraph replay of the launches after the sweep "
+                         "(debug_flags bit 5): less host time per image")
     ap.add_argument("--wire", default="runs", choices=["runs", "int16"],
                     help="wire format of the mask exchange for N > 1 (run-length change points | int16 map)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -159,7 +162,9 @@ def main():
     # per-phase report), so that the host does not become the bottleneck of the loop it measures
     opts_lean = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                     merge_logprob_bias=OPTS[2], mode=args.mode,
-                                    debug_flags=2 if args.no_kernel_events else 16)
+                                    debug_flags=2 if args.no_kernel_events else (48 if args.replay else 16))
+    ring_out = [(torch.empty((H, W), dtype=torch.int32, device=dev), torch.empty((H * W,), dtype=torch.int32, device=dev))
+                for _ in range(max(1, args.contexts))] if args.replay else None
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
     ex = MaskExchange(H, W, dev, fmt=args.wire, merger=merger) if world > 1 else None
@@ -195,7 +200,8 @@ def main():
             for i in range(first, first + count):
                 cp, sp = pool_images[i % POOL]
                 ring.append(mergers_ring[i % len(mergers_ring)].segment_async(
-                    cp, sp, offs, opts if (i - first) % EVENTS_EVERY == 0 else opts_lean))
+                    cp, sp, offs, opts if (i - first) % EVENTS_EVERY == 0 else opts_lean,
+                    out=ring_out[i % len(mergers_ring)] if ring_out else None))
                 if len(ring) >= len(mergers_ring):
                     collect(ring.popleft().result())
             while ring:

@@ -88,7 +88,11 @@ typedef struct mn_options {
                                   general rounds from single pixels instead of from the cores; bit 3: no
                                   contraction of order-free clusters in the general rounds; bit 4: only
                                   the sweep is timed (ms_cc_edges; the other ms_* stay 0) -- an event
-                                  costs the host ~3.5 us to record and ~8 us to read               */
+                                  costs the host ~3.5 us to record and ~8 us to read; bit 5 (with
+                                  bit 4): replay -- when mn_segment_launch is called again with the
+                                  same buffers, shape, options and stream, the launches after the
+                                  sweep are recorded into two hipGraphs (second call) and replayed
+                                  (from the third): a loop over images through fixed buffers        */
   int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
                                   order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
                                   has at most exact_limit_proof initial records, else the call returns

@@ -31,6 +31,8 @@ MN_VARIANT_PYSEGMENTER = 1
 MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS, MN_MODE_COMPONENTS = 0, 1, 2, 3
 MN_ERR_NO_BACKGROUND = -10
 MN_ERR_UNPROVEN = -30
+MN_DEBUG_GENERIC_EDGE_PASS, MN_DEBUG_NO_EVENTS, MN_DEBUG_NO_CORES, MN_DEBUG_NO_CLUSTERS = 1, 2, 4, 8
+MN_DEBUG_LEAN_EVENTS, MN_DEBUG_REPLAY = 16, 32
 MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
 
 SegmenterOptions = namedtuple("SegmenterOptions",
@@ -405,18 +407,29 @@ class Merger:
         return mask, table, part, stats.as_dict()
 
     def segment_async(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None,
-                      want_partition: bool = False) -> "PendingSegment":
+                      want_partition: bool = False, out=None) -> "PendingSegment":
         """Queue one image (``mn_segment_launch``) and return at once; ``.result()`` of the returned
         object waits and gives what :meth:`segment` gives.  The Merger is busy until then -- use
         two of them alternately on one stream to keep the GPU busy across images: the launch of
         image i+1 then precedes the read-back of image i, and kernels of different images still
-        do not overlap (their timings stay clean)."""
+        do not overlap (their timings stay clean).
+
+        ``out=(mask, table)`` (int32 [H,W] and [H*W] tensors of the caller) receives the result instead
+        of fresh tensors.  A serving loop that feeds the same input and output buffers every time can
+        add ``MN_DEBUG_REPLAY | MN_DEBUG_LEAN_EVENTS`` to ``opts.debug_flags``: from the third such call
+        on, the library replays two recorded hipGraphs instead of issuing ~17 launches."""
         torch = self.torch
         C, H, W, O, off = self._check(class_probs, same_probs, offsets)
         opts = opts if opts is not None else default_options()
         dev = class_probs.device
-        mask = torch.empty((H, W), dtype=torch.int32, device=dev)
-        table = torch.empty((H * W,), dtype=torch.int32, device=dev)
+        if out is not None:
+            mask, table = out[0], out[1]
+            if not (mask.is_cuda and mask.dtype == torch.int32 and mask.is_contiguous() and mask.numel() == H * W
+                    and table.is_cuda and table.dtype == torch.int32 and table.numel() >= H * W):
+                raise ValueError("out=(mask int32 [H,W], table int32 [H*W]) on the GPU")
+        else:
+            mask = torch.empty((H, W), dtype=torch.int32, device=dev)
+            table = torch.empty((H * W,), dtype=torch.int32, device=dev)
         part = torch.empty((H, W), dtype=torch.int32, device=dev) if want_partition else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.mn_segment_launch(self.handle, class_probs.data_ptr(), C,

@@ -659,3 +659,29 @@ def test_require_proof_routes_to_the_sequential_order_or_says_no(oracle):
     mask, classes, part, st = _run(g, seg.MN_MODE_AUTO, require_proof=1)
     assert st["proof"] == seg.MN_PROOF_CERTIFICATE and st["certified"] == 1
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_replay_of_recorded_graphs_gives_the_same_result():
+    """debug_flags bit 5: from the third call through the same buffers the launches after the sweep are
+    replayed from two recorded hipGraphs; the result must not change, and a call with other buffers
+    must not use the old recording."""
+    import torch
+    offs = synth.generate_offsets(40, 10)
+    H, W, C = 256, 512, 9
+    imgs = []
+    for sd in (1000, 1001):
+        s = synth.synth_v1(H, W, C, offs, sd)
+        imgs.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
+    m = seg.Merger(H, W, C, len(offs))
+    plain = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_COMPONENTS)
+    refs = [m.segment(cp, sp, offs, plain) for cp, sp in imgs]
+    assert refs[0][3]["mode_used"] == seg.MN_MODE_COMPONENTS
+    o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_COMPONENTS,
+                            debug_flags=seg.MN_DEBUG_LEAN_EVENTS | seg.MN_DEBUG_REPLAY)
+    out = (torch.empty((H, W), dtype=torch.int32, device="cuda"), torch.empty((H * W,), dtype=torch.int32, device="cuda"))
+    for which in (0, 0, 0, 0, 1, 1, 1, 0, 0, 0):
+        out[0].zero_()
+        mask, table, _, st = m.segment_async(imgs[which][0], imgs[which][1], offs, o, out=out).result()
+        rm, rt, _, rs = refs[which]
+        assert st["num_instances"] == rs["num_instances"] and st["total_logprob"] == rs["total_logprob"]
+        assert torch.equal(mask, rm) and torch.equal(table[:st["num_instances"]], rt[:rs["num_instances"]])

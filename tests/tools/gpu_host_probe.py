@@ -11,9 +11,10 @@ imgs = []
 for sd in (1000, 1001, 1002, 1003):
     s = synth.synth_v1(H, W, C, offs, sd)
     imgs.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
-for nctx in (4, 6):
+for nctx in (4,):
     ring_m = [seg.Merger(H, W, C, len(offs)) for _ in range(nctx)]
-    for flags in (0, 2):
+    outs = [(torch.empty((H, W), dtype=torch.int32, device='cuda'), torch.empty((H * W,), dtype=torch.int32, device='cuda')) for _ in range(nctx)]
+    for flags in (0, 16, 16 | 32):
         opts = seg.default_options(merge_logprob_bias=0.03, debug_flags=flags)
         for rep in range(2):
             ring = deque(); tl = tr = 0.0
@@ -21,7 +22,7 @@ for nctx in (4, 6):
             n = 1000
             for i in range(n):
                 a = time.perf_counter()
-                ring.append(ring_m[i % nctx].segment_async(*imgs[i % 4], offs, opts))
+                ring.append(ring_m[i % nctx].segment_async(*imgs[i % 4], offs, opts, out=outs[i % nctx]))
                 b = time.perf_counter(); tl += b - a
                 if len(ring) >= nctx:
                     ring.popleft().result()
@@ -29,3 +30,14 @@ for nctx in (4, 6):
             while ring: ring.popleft().result()
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print("contexts %d flags %d: %.1f us/step; host in launch %.1f us, in read-back %.1f us" % (nctx, flags, dt / n * 1e6, tl / n * 1e6, tr / n * 1e6), flush=True)
+
+# the replayed result equals the ordinary one
+m = seg.Merger(H, W, C, len(offs))
+ref, tab, _, st0 = m.segment(*imgs[1], offs, seg.default_options(merge_logprob_bias=0.03))
+o = seg.default_options(merge_logprob_bias=0.03, debug_flags=48)
+out = (torch.empty((H, W), dtype=torch.int32, device='cuda'), torch.empty((H * W,), dtype=torch.int32, device='cuda'))
+for k in range(5):
+    out[0].zero_()
+    mk, tb, _, st = m.segment_async(*imgs[1], offs, o, out=out).result()
+    print("call %d: equal %s, instances %d (%d), loglik %.6f (%.6f), ms_cc_edges %.4f" % (k, bool(torch.equal(mk, ref)) and bool(torch.equal(tb[:st["num_instances"]], tab[:st0["num_instances"]])),
+          st["num_instances"], st0["num_instances"], st["total_logprob"], st0["total_logprob"], st["ms_cc_edges"]), flush=True)
