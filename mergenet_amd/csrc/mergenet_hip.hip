@@ -245,7 +245,21 @@ static int ctx_alloc(mn_context* c) {
   for (int i = 0; i < 12; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   MN_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  MN_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  {
+    // The tail of an image runs beside the NEXT images' sweeps.  MN_SIDE_PRIORITY=low in the environment
+    // puts it on a stream of the lowest priority the device offers: the sweeps then run undisturbed
+    // (52 instead of 60 us by events), but an image's tail takes longer, and with the ring of three
+    // contexts of bench.py the loop as a whole was slower (12.0 against 14.3 Gpixel/s; with four
+    // contexts 13.6 against 12.3): default priority unless asked.
+    int lo = 0, hi = 0;
+    const char* e = getenv("MN_SIDE_PRIORITY");
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+    if (!(e && e[0] == 'l')) lo = 0;
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo) != hipSuccess) {
+      (void)hipGetLastError();
+      MN_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    }
+  }
   MN_HIP(hipStreamCreateWithFlags(&c->replay.cap, hipStreamNonBlocking));
   return MN_OK;
 }
