@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
-    ap.add_argument("--contexts", type=int, default=3,
+    ap.add_argument("--contexts", type=int, default=8,
                     help="merger contexts in rotation on the one compute stream (launch of image i precedes the "
                          "read-back of image i - contexts + 1)")
     ap.add_argument("--replay", action="store_true",

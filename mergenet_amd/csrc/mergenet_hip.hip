@@ -246,15 +246,15 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   MN_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   {
-    // The tail of an image runs beside the NEXT images' sweeps.  MN_SIDE_PRIORITY=low in the environment
-    // puts it on a stream of the lowest priority the device offers: the sweeps then run undisturbed
-    // (52 instead of 60 us by events), but an image's tail takes longer, and with the ring of three
-    // contexts of bench.py the loop as a whole was slower (12.0 against 14.3 Gpixel/s; with four
-    // contexts 13.6 against 12.3): default priority unless asked.
+    // The tail of an image runs beside the NEXT images' sweeps and should not take compute units from
+    // them: its stream gets the lowest priority the device offers (sweep 53 instead of 57-60 us by
+    // events in bench.py's ring).  How that plays out for a whole loop depends on the ring depth
+    // (tests/tools/gpu_ring_sweep.sh, Gpixel/s low / default priority: 2 contexts 11.9 / 11.9, 3 contexts
+    // 12.0 / 14.3, 4 contexts 13.6 / 12.3); MN_SIDE_PRIORITY=default in the environment switches it off.
     int lo = 0, hi = 0;
     const char* e = getenv("MN_SIDE_PRIORITY");
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
-    if (!(e && e[0] == 'l')) lo = 0;
+    if (e && e[0] == 'd') lo = 0;
     if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo) != hipSuccess) {
       (void)hipGetLastError();
       MN_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
