@@ -665,6 +665,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // caller's fill
   HashTab T = c->T;
   T.mask = (unsigned)(c->cc_cap - 1);
+  // end of the labelling stages, on the stream they ran on (the side stream starts when it gets the chip)
+  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[7], st));
   if (fork_before_sums) {
     // From here on the image is latency-bound work of a few workgroups (and one pixel-wide mask
     // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
@@ -678,7 +680,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
       st = c->replay.cap;
     }
   }
-  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[7], st));
+  if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[11], st));
   {
     const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
     if (lds > c->cc_sum_lds) {
@@ -785,7 +787,7 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
       (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[10]); stats->ms_cc_edges = ms;
       if (!(opts->debug_flags & 16)) {
         (void)hipEventElapsedTime(&ms, c->ev[10], c->ev[7]); stats->ms_cc_label = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[7], c->ev[8]); stats->ms_cc_sums = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[11], c->ev[8]); stats->ms_cc_sums = ms;
         (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]); stats->ms_cc_cross = ms;
       }
     }
