@@ -97,6 +97,11 @@ typedef struct mn_options {
                                   order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
                                   has at most exact_limit_proof initial records, else the call returns
                                   MN_ERR_UNPROVEN -- the library says no instead of guessing       */
+  int core_radius;             /* general rounds: an offset counts as SHORT when both its components
+                                  are at most this many pixels; a pixel is clean -- and may join a core
+                                  ahead of the rounds -- when all its short edges are positive and
+                                  same-class (0 = default; < 0 = every offset
+                                  is short: the widest fringe, the closest to the reference's order)   */
 } mn_options;
 
 typedef struct mn_stats {

@@ -62,6 +62,7 @@ struct mn_context {
   int* fin_lists;         // 3 * MN_FIN2_MAXR ints: scratch lists of the LDS finisher
   int fin_lds_ready, tail_lds_ready;
   int* wire_counts;       // block counts + total of mn_pack_runs_device (apart from the image's own scratch)
+  int core_radius;        // short-offset radius of the cores (mn_options::core_radius resolved)
   int cores_used;         // the last attempt ran the general rounds from the cores (mn_core_clean)
   int cc_clean;           // 1: counters and the speculative record table were cleared at the end of the last image
   HashTab T;
@@ -134,6 +135,8 @@ struct mn_context {
   float *d_class, *d_same;
   int *d_mask, *d_objcls, *d_part;
 };
+
+#define MN_DEFAULT_CORE_RADIUS 6
 
 static size_t next_pow2(size_t x) {
   size_t p = 1;
@@ -622,16 +625,20 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   if (!few_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
   const unsigned* lbits = c->cc_bits;
+  unsigned kshort = 0u;
   if (cores) {
     if (!fused_cls) {                // (the class sweep of this form comes after the labelling)
       const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256);
       hipLaunchKernelGGL(mn_class_pass, dim3(blocks), dim3(256), 0, st, P, c->cls0);
     }
     unsigned* bits2 = reinterpret_cast<unsigned*>(c->label);      // free until the finisher
+    // short offsets: within 3 pixels (the unit offsets are among them); bit 6: all offsets count as short
+    for (int k = 0; k < P.O; k++)
+      if (c->core_radius < 0 || (abs(P.di[k]) <= c->core_radius && abs(P.dj[k]) <= c->core_radius)) kshort |= 1u << k;
     hipLaunchKernelGGL(mn_core_clean, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned*)c->cc_bits,
-                       (const unsigned char*)c->cls0, c->pruned);
-    hipLaunchKernelGGL(mn_core_bits, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned char*)c->pruned, bits2,
-                       c->touch);                   // (cleared by the caller's fill)
+                       (const unsigned char*)c->cls0, c->pruned, kshort);
+    hipLaunchKernelGGL(mn_core_bits, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned char*)c->pruned,
+                       (const unsigned*)c->cc_bits, (const unsigned char*)c->cls0, bits2);
     lbits = bits2;
   }
   // (labelling the tiles inside the sign sweep -- a block = a 16 x 64 tile -- was tried: 40.6 us for
@@ -712,6 +719,17 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
                      (const unsigned char*)c->matched, (const i64*)c->lp_acc,
                      (const int*)clsmin, (const int*)clsmax, c->mate, cores ? (int*)nullptr : c->cc_roots,
                      c->scalars + 8, c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
+  if (cores) {
+    const unsigned all = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
+    if (kshort != all) {           // a core with a non-positive edge inside falls apart again
+      MN_HIP(hipMemsetAsync(c->matched, 0, (size_t)N, st));      // (the root candidates are done with)
+      hipLaunchKernelGGL(mn_core_check, dim3(grid_for(N, 256)), b, 0, st, P, (const int*)c->parent, lbits, c->matched);
+      hipLaunchKernelGGL(mn_core_dissolve, dim3(grid_for(N, 256)), b, 0, st, P, S,
+                         (const unsigned char*)c->matched, c->scalars + 9);
+    }
+    // what mn_build_from_pixels will insert: sizes its table (c->touch was cleared by the caller's fill)
+    hipLaunchKernelGGL(mn_count_cross_edges, dim3(grid_for(N, 256)), b, 0, st, P, (const int*)c->parent, c->touch);
+  }
   if (with_compact)                // (mn_cc_tail takes the table itself)
     hipLaunchKernelGGL(mn_compact<4>, dim3(grid_for(c->cc_cap, MN_COMPACT_SLOTS)), dim3(256), 0, st, P, S,
                        T, c->LA, with_ball ? c->ball : (u64*)nullptr, c->gmax, c->cnt,
@@ -816,6 +834,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
   c->debug_flags = opts->debug_flags;
+  c->core_radius = opts->core_radius != 0 ? opts->core_radius : MN_DEFAULT_CORE_RADIUS;
   const int N = P.N;
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;

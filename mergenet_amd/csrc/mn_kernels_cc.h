@@ -541,9 +541,14 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
 
 // ---- cores: the contraction as the FIRST step of the general rounds --------------------------------
 // A map that is not sign-separable as a whole still is inside its instances: a pixel is CLEAN when
-// every in-bounds edge it takes part in (as source or as target, all offsets) is positive beyond the
-// margin and joins two pixels of one arg-max class.  The clean pixels joined by edges between clean
-// pixels form the cores.  Inside a core every record between sub-objects is positive with class
+// every in-bounds edge of a SHORT offset it takes part in (as source or as target) is positive beyond
+// the margin and joins two pixels of one arg-max class.  The clean pixels joined by positive same-class
+// edges (all offsets) between clean pixels form the cores; a core inside which some edge is not
+// positive is condemned and falls apart again (mn_core_check).  (With all offsets counted as short --
+// mn_options::core_radius < 0 -- a clean pixel has no non-positive edge at all and no core can be
+// condemned; that leaves a fringe as wide as the LONGEST offset around every instance, 40 pixels at the
+// benchmark's offsets, where a short radius leaves the few pixels the maps are unsure about -- and
+// moves further from the reference's order)  Inside a core every record between sub-objects is positive with class
 // delta 0 whatever the order (the argument of conditions (a) and (c) above), so the reference merges
 // each core completely sooner or later; the rounds start from the cores plus the single pixels of the
 // fringe (the band of the largest offset's width along instance boundaries, and whatever noise
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
 // approximation of the reference's order elsewhere, like the rounds themselves.
 __global__ __launch_bounds__(256) void mn_core_clean(ImgParams P, const unsigned* __restrict__ bits,
                                                      const unsigned char* __restrict__ cls0,
-                                                     unsigned char* __restrict__ clean) {
+                                                     unsigned char* __restrict__ clean, unsigned kshort) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.N) return;
   const int r = p / P.W, c = p - r * P.W;
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(256) void mn_core_clean(ImgParams P, const unsigned
   const unsigned char mine = cls0[p];
   bool ok = true;
   for (int k = 0; k < P.O; k++) {
+    if (!((kshort >> k) & 1u)) continue;
     const int di = P.di[k], dj = P.dj[k];
     if (r + di >= 0 && r + di < P.H && c + dj >= 0 && c + dj < P.W) {
       const int q = p + di * P.W + dj;
@@ -574,29 +580,81 @@ __global__ __launch_bounds__(256) void mn_core_clean(ImgParams P, const unsigned
   clean[p] = ok ? 1 : 0;
 }
 
-// out-edges between two clean pixels, in the format of the sign sweep's masks (a set bit implies an
-// in-bounds neighbour): what the labelling stages run on
-// `outside` (64 words): in-bounds edges that are NOT between two clean pixels -- an upper bound of the
-// records the rounds start with, which sizes their first table
+// positive same-class out-edges (ALL offsets) between two clean pixels, in the format of the sign
+// sweep's masks (a set bit implies an in-bounds neighbour): what the labelling stages run on
 __global__ __launch_bounds__(256) void mn_core_bits(ImgParams P, const unsigned char* __restrict__ clean,
-                                                    unsigned* __restrict__ bits2,
-                                                    unsigned* __restrict__ outside) {
+                                                    const unsigned* __restrict__ bits,
+                                                    const unsigned char* __restrict__ cls0,
+                                                    unsigned* __restrict__ bits2) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  unsigned m = 0u;
+  if (clean[p]) {
+    const unsigned b = bits[p];
+    const unsigned char mine = cls0[p];
+    const int r = p / P.W, c = p - r * P.W;
+    for (int k = 0; k < P.O; k++) {
+      if (!((b >> k) & 1u)) continue;                   // (a set bit implies an in-bounds neighbour)
+      const int q = (r + P.di[k]) * P.W + c + P.dj[k];
+      if (clean[q] && cls0[q] == mine) m |= 1u << k;
+    }
+  }
+  bits2[p] = m;
+}
+
+// With `kshort` a subset of the offsets (the short ones), a core may hold two pixels joined by an edge
+// that is NOT positive (a long offset reaching across a thin bridge): then the records inside the core
+// are not all positive and the argument above fails -- for THAT core.  Every in-bounds edge between
+// two pixels of one core must be in the core's mask; a core with one that is not is condemned.
+__global__ __launch_bounds__(256) void mn_core_check(ImgParams P, const int* __restrict__ parent,
+                                                     const unsigned* __restrict__ bits2,
+                                                     unsigned char* __restrict__ condemned) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  const int root = parent[p];
+  const unsigned b = bits2[p];
+  const int r = p / P.W, c = p - r * P.W;
+  for (int k = 0; k < P.O; k++) {
+    if ((b >> k) & 1u) continue;
+    const int rr = r + P.di[k], cc = c + P.dj[k];
+    if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
+    if (parent[rr * P.W + cc] == root) { condemned[root] = 1; return; }
+  }
+}
+
+// condemned cores fall apart into single pixels again (sizes 1, class sums read from the planes)
+__global__ __launch_bounds__(256) void mn_core_dissolve(ImgParams P, ObjState S,
+                                                        const unsigned char* __restrict__ condemned,
+                                                        int* __restrict__ ndissolved) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  const int root = S.parent[p];
+  if (!condemned[root]) return;
+  // (the root's own entry is rewritten by the root's thread: every pixel of the core reads
+  //  condemned[root], which nobody clears, and parent[p] only of itself)
+  S.parent[p] = p;
+  S.osize[p] = 1;
+  S.lpvalid[p] = 0;
+  if (p == root) *ndissolved = 1;
+}
+
+// in-bounds pixel edges between different objects: the number of insertions mn_build_from_pixels will
+// make, which sizes its table (64 words, one atomic per block)
+__global__ __launch_bounds__(256) void mn_count_cross_edges(ImgParams P, const int* __restrict__ parent,
+                                                            unsigned* __restrict__ outside) {
   __shared__ int sh_n;
   if (threadIdx.x == 0) sh_n = 0;
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   int out = 0;
   if (p < P.N) {
-    unsigned m = 0u;
-    const bool mine = clean[p] != 0;
+    const int u = parent[p];
     const int r = p / P.W, c = p - r * P.W;
     for (int k = 0; k < P.O; k++) {
       const int rr = r + P.di[k], cc = c + P.dj[k];
       if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) continue;
-      if (mine && clean[rr * P.W + cc]) m |= 1u << k;
-      else out++;
+      out += parent[rr * P.W + cc] != u ? 1 : 0;
     }
-    bits2[p] = m;
   }
   for (int off = 32; off > 0; off >>= 1) out += __shfl_xor(out, off);
   if ((threadIdx.x & 63) == 0 && out) atomicAdd(&sh_n, out);

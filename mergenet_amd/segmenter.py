@@ -47,7 +47,7 @@ class MnOptions(ctypes.Structure):
                 ("subrounds", ctypes.c_int), ("prune_threshold", ctypes.c_float),
                 ("compute_logprob", ctypes.c_int), ("no_handover_refresh", ctypes.c_int),
                 ("band_permille", ctypes.c_int), ("debug_flags", ctypes.c_int),
-                ("require_proof", ctypes.c_int)]
+                ("require_proof", ctypes.c_int), ("core_radius", ctypes.c_int)]
 
 
 class MnStats(ctypes.Structure):

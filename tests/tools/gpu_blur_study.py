@@ -61,7 +61,8 @@ if __name__ == "__main__":
             for mode in ((seg.MN_MODE_EXACT, seg.MN_MODE_ROUNDS) if H * W <= 16384 else (seg.MN_MODE_AUTO, seg.MN_MODE_ROUNDS)):
                 o = seg.default_options(mode=mode, clip_inputs=1, band_permille=int(__import__('os').environ.get('MN_BAND', '0')),
                                         subrounds=int(__import__('os').environ.get('MN_SUB', '0')),
-                                        finish_limit=int(__import__('os').environ.get('MN_FINISH', '0')))
+                                        finish_limit=int(__import__('os').environ.get('MN_FINISH', '0')),
+                                        core_radius=int(__import__('os').environ.get('MN_CORE', '0')))
                 mask, classes, part, st = ctx.segment(cp, sp, offs, o)
                 got[(sd, mode)] = (mask, classes, st)
         res = pending.get()

@@ -14,7 +14,7 @@ small += [n for n in gu.names("cseg_") if ("n35" in n or "n60" in n or "noise" i
 
 
 def run(ctx, g, flags, **kw):
-    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=flags, **kw)
+    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, core_radius=flags, **kw)
     mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
     eq = labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])
     agree = labels.agreement(mask, g["mask"])
@@ -31,7 +31,7 @@ for group in (small, big):
         if key not in ctxs:
             ctxs[key] = seg.HostContext(H, W, C, O)
         ctx = ctxs[key]
-        for flags, tag in ((8, "noclus"), (0, "clust ")):
+        for flags, tag in ((-1, "strict"), (10, "r10   "), (6, "r6    ")):
             run(ctx, g, flags)
             eq, agree, st, K = run(ctx, g, flags)
             print("%-34s %s: equal %d  agree %8d / %8d (%.4f %%)  K %3d (ref %3d)  %.2f ms  rounds %3d  steps %5d  records %d" % (
@@ -40,14 +40,14 @@ for group in (small, big):
     ctxs.clear()
 
 # a network-like map at the benchmark size (no reference vector: 435 s per image on the CPU)
-offs = synth.generate_offsets(20, 10)
+offs = synth.generate_offsets(40, 10)
 s = synth.blurred_v1(1024, 2048, 9, offs, 4242, radius=2, noise=0.05)
 ctx = seg.HostContext(1024, 2048, 9, 10)
 res = {}
-for flags, tag in ((8, "noclus"), (0, "clust ")):
-    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=flags)
+for flags, tag in ((-1, "strict"), (10, "r10   "), (6, "r6    ")):
+    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, core_radius=flags)
     ctx.segment(s.class_probs, s.sameness_probs, offs, o)
     mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
     res[tag] = mask
     print("blurred 1024x2048 %s: K %d  %.2f ms  rounds %d  steps %d" % (tag, len(classes), st["ms_total"], st["rounds"], st["finisher_steps"]), flush=True)
-print("blurred 1024x2048: the two agree on %d of %d pixels" % (labels.agreement(res["noclus"], res["clust "]), 1024 * 2048))
+print("blurred 1024x2048: the two agree on %d of %d pixels" % (labels.agreement(res["strict"], res["r6    "]), 1024 * 2048))
