@@ -70,7 +70,8 @@ typedef struct mn_options {
   int clip_inputs;             /* 1: clip to [2^-23, 1-2^-23] on load (c_segment.pyx:53-55 fused) */
   int exact_limit;             /* AUTO: max initial records for exact mode (0 = default 32768)   */
   int finish_limit;            /* ROUNDS: hand over to the sequential finisher at <= this many
-                                  live records (0 = default 4096)                                */
+                                  live records (0 = default: 2048 in the rounds, 4096 records
+                                  between components in components mode)                         */
   int subrounds;               /* ROUNDS: matching sub-rounds per round (0 = default 32)         */
   float prune_threshold;       /* pysegmenter prune threshold (segmenter.py:351; default 200)    */
   int compute_logprob;         /* 1: also evaluate the total log-likelihood (segment.cc:314-350) and

@@ -839,6 +839,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   const long long R0 = count_records(W, H, offset_dim, offset_list);
   const int exact_limit = opts->exact_limit > 0 ? opts->exact_limit : 32768;
   const int finish_limit = opts->finish_limit > 0 ? opts->finish_limit : 4096;
+  // hand-over of the general rounds: since the rounds start from the cores a late round is cheap, and
+  // 2048 records beat 4096 (10.0 against 11.6 ms on a blurred 1024x2048 map; 1536: 9.7 ms)
+  const int rounds_limit = opts->finish_limit > 0 ? opts->finish_limit : 2048;
   int subrounds = opts->subrounds > 0 ? opts->subrounds : 32;
   if (subrounds > MN_MAX_SUBROUNDS) subrounds = MN_MAX_SUBROUNDS;
   const float band_gamma = opts->band_permille > 0 ? opts->band_permille * 1e-3f
@@ -990,7 +993,11 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
     bool first_round = true;
     int productive = subrounds;    // matching sub-rounds of the previous round that paired anything, + 1
-    while (!speculate && R > finish_limit && rounds < 5000) {
+    // (a list the finisher can take whole goes to it at once: the sequential order itself; the lower
+    //  hand-over only applies once the rounds are running)
+    int loop_limit = finish_limit;
+    while (!speculate && R > loop_limit && rounds < 5000) {
+      if (mode != MN_MODE_COMPONENTS || rounds > 0) loop_limit = rounds_limit;
       {
         FillList f;                // one launch instead of five memsets
         f.add(c->matched, N, 0);

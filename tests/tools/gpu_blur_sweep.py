@@ -8,7 +8,7 @@ offs = synth.generate_offsets(40, 10)
 s = synth.blurred_v1(1024, 2048, 9, offs, 4242, radius=2, noise=0.05)
 ctx = seg.HostContext(1024, 2048, 9, 10)
 base = None
-for kw in (dict(), dict(band_permille=50), dict(band_permille=20), dict(band_permille=10), dict(band_permille=50, finish_limit=2048)):
+for kw in (dict(), dict(finish_limit=3072), dict(finish_limit=2048), dict(finish_limit=1536), dict(finish_limit=6144), dict(band_permille=100), dict(band_permille=20)):
     o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, **kw)
     ctx.segment(s.class_probs, s.sameness_probs, offs, o)
     mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
@@ -21,9 +21,9 @@ for kw in (dict(), dict(band_permille=50), dict(band_permille=20), dict(band_per
 import golden_util as gu
 for name in ("cseg_synth_1024x2048_cfg2", "cseg_synth_1024x2048_s1003"):
     g = gu.load(name)
-    for fl in (100, 50, 20, 10):
-        o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, band_permille=fl)
+    for fl in (4096, 2048):
+        o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, finish_limit=fl)
         ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
-        print("%s band %d: equal %d  %.2f ms rounds %d steps %d" % (name, fl, labels.masks_equivalent(mask, classes, g["mask"], g["object_class"]),
+        print("%s finish_limit %d: equal %d  %.2f ms rounds %d steps %d" % (name, fl, labels.masks_equivalent(mask, classes, g["mask"], g["object_class"]),
               st["ms_total"], st["rounds"], st["finisher_steps"]), flush=True)
