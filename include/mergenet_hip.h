@@ -136,7 +136,9 @@ typedef struct mn_stats {
                                   inputs), 1 = certificate (ANY order of the lazy greedy ends here,
                                   DESIGN.md section 5), 2 = the sequential order itself was run
                                   (MN_MODE_EXACT; ties between bit-equal priorities aside)         */
-  int reserved_i[3];
+  int cores_condemned;         /* general rounds: 1 if a core held an edge that was not positive and
+                                  fell apart again (mn_core_check); 0 otherwise                    */
+  int reserved_i[2];
 } mn_stats;
 
 typedef struct mn_context mn_context;

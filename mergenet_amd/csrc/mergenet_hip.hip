@@ -780,6 +780,7 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->num_instances = c->h_scalars[1];
     stats->num_objects = c->h_scalars[2];
     stats->rounds = rounds;
+    stats->cores_condemned = c->cores_used ? (c->h_scalars[9] != 0) : 0;
     stats->finisher_steps = c->h_cnt->finisher_steps;
     stats->initial_records = R0;
     stats->merges = merges;

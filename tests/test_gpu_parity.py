@@ -685,3 +685,43 @@ def test_replay_of_recorded_graphs_gives_the_same_result():
         rm, rt, _, rs = refs[which]
         assert st["num_instances"] == rs["num_instances"] and st["total_logprob"] == rs["total_logprob"]
         assert torch.equal(mask, rm) and torch.equal(table[:st["num_instances"]], rt[:rs["num_instances"]])
+
+
+def test_core_with_a_non_positive_edge_inside_falls_apart(oracle):
+    """Two same-class instances side by side whose SHORT edges are made positive across a stretch of
+    their common boundary: the clean pixels chain across, the core holds long edges that are negative,
+    mn_core_check condemns it, and the rounds start from single pixels there.  The result must stay a
+    valid answer close to the reference's; without the bridge no core is condemned."""
+    offs = synth.generate_offsets(20, 10)
+    H, W, C = 48, 96, 3
+    inst = np.zeros((H, W), np.int32)
+    inst[:, : W // 2] = 1
+    inst[:, W // 2:] = 2
+    cp = np.full((C, H, W), 0.05, np.float32)
+    cp[1] = 0.9                                             # both halves of class 1
+    rng = np.random.default_rng(5)
+    short = [k for k, (di, dj) in enumerate(offs) if abs(di) <= 6 and abs(dj) <= 6]
+
+    def maps(bridge):
+        sp = np.ones((len(offs), H, W), np.float32)
+        for k, (di, dj) in enumerate(offs):
+            r0, r1 = max(0, -di), min(H, H - di)
+            c0, c1 = max(0, -dj), min(W, W - dj)
+            same = inst[r0:r1, c0:c1] == inst[r0 + di:r1 + di, c0 + dj:c1 + dj]
+            sp[k, r0:r1, c0:c1] = np.where(same, 0.9, 0.1)
+        if bridge:
+            for k in short:
+                sp[k, 16:32, W // 2 - 8: W // 2 + 8] = 0.8    # every short edge near the boundary says "same"
+        sp += rng.uniform(-0.03, 0.03, sp.shape).astype(np.float32)
+        return np.clip(sp, 0.01, 0.99).astype(np.float32)
+
+    for bridge in (False, True):
+        sp = maps(bridge)
+        ref = oracle.run_csegment(cp, sp, C, offs, 0.0, 1.0, 0.03)
+        ctx = seg.HostContext(H, W, C, len(offs))
+        o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8)
+        mask, classes, part, st = ctx.segment(cp, sp, offs, o)
+        ctx.close()
+        assert st["status"] == 0 and st["cores_condemned"] == (1 if bridge else 0), st
+        assert mask.min() >= 0 and mask.max() == len(classes) == st["num_instances"]
+        assert labels.agreement(mask, ref.mask) >= 0.97 * mask.size, (bridge, st, len(ref.object_class))
