@@ -81,7 +81,7 @@ struct mn_context {
   Counters* h_cnt;        // pinned host mirror
   int* h_scalars;         // pinned
   double* h_lp;           // pinned
-  size_t cc_sum_lds;
+  size_t cc_sum_lds, oc_lds;
   // counters, scalars and log-likelihood outputs live in ONE device block mirrored by ONE pinned
   // host block, so that the statistics of an image come back in a single copy
   unsigned char* statblk;
@@ -550,6 +550,11 @@ static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, 
   hipLaunchKernelGGL(mn_oc_clear, go, b, 0, st, P, (const int*)c->parent, (const int*)up,
                      (const unsigned char*)bad, c->lp_acc);
   const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
+  if (lds > c->oc_lds) {             // (127 classes: 64 KiB of table, more than a kernel gets unasked)
+    MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_oc_gather),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->oc_lds = lds;
+  }
   hipLaunchKernelGGL(mn_oc_gather, dim3(grid_for(N, MN_OC_THREADS)), dim3(MN_OC_THREADS), lds, st, P, S,
                      (const int*)up, (const unsigned char*)bad, c->lp_acc, c->matched, c->cnt);
   hipLaunchKernelGGL(mn_oc_finish, go, b, 0, st, P, S, (const i64*)c->lp_acc, (const unsigned char*)c->matched);
