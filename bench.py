@@ -101,6 +101,12 @@ def main():
     ap.add_argument("--contexts", type=int, default=8,
                     help="merger contexts in rotation on the one compute stream (launch of image i precedes the "
                          "read-back of image i - contexts + 1)")
+    ap.add_argument("--spin-seconds", type=float, default=2.5,
+                    help="untimed: run the loop this long before the warm-up steps, so that the timed steps see "
+                         "the GPU's sustained clocks instead of its idle power state")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="compute streams the ring's contexts are dealt over (1: every sweep runs alone on the "
+                         "one compute stream and its HIP-event duration is the kernel's)")
     ap.add_argument("--replay", action="store_true",
                     help="fixed output buffers per context + hipGraph replay of the launches after the sweep "
                          "(debug_flags bit 5): less host time per image")
@@ -165,6 +171,7 @@ def main():
                                     debug_flags=2 if args.no_kernel_events else (48 if args.replay else 16))
     ring_out = [(torch.empty((H, W), dtype=torch.int32, device=dev), torch.empty((H * W,), dtype=torch.int32, device=dev))
                 for _ in range(max(1, args.contexts))] if args.replay else None
+    ring_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(max(1, args.streams) - 1)]
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
     ex = MaskExchange(H, W, dev, fmt=args.wire, merger=merger) if world > 1 else None
@@ -199,9 +206,11 @@ def main():
             ring = deque()
             for i in range(first, first + count):
                 cp, sp = pool_images[i % POOL]
-                ring.append(mergers_ring[i % len(mergers_ring)].segment_async(
-                    cp, sp, offs, opts if (i - first) % EVENTS_EVERY == 0 else opts_lean,
-                    out=ring_out[i % len(mergers_ring)] if ring_out else None))
+                k = i % len(mergers_ring)
+                with torch.cuda.stream(ring_streams[k % len(ring_streams)]):
+                    ring.append(mergers_ring[k].segment_async(
+                        cp, sp, offs, opts if (i - first) % EVENTS_EVERY == 0 else opts_lean,
+                        out=ring_out[k] if ring_out else None))
                 if len(ring) >= len(mergers_ring):
                     collect(ring.popleft().result())
             while ring:
@@ -233,6 +242,19 @@ def main():
     if ex is not None:
         zmask = torch.zeros((H, W), dtype=torch.int32, device=dev)
         ex.result(ex.submit(zmask, torch.zeros((1,), dtype=torch.int32, device=dev), 0))
+    # ... and the GPU's power state: after the seconds of host work above (map generation, upload) the
+    # chip sits at idle clocks, and a few milliseconds of warm-up steps do not bring them up -- the same
+    # 2000 timed steps ran at 0.176 ms behind 20 warm-up steps and at 0.141 ms behind 20000 (the
+    # bandwidth-bound sweep took 53.9 us either way: it is the latency-bound kernels that follow the
+    # core clock).  A service that merges images all day runs at the sustained clocks, so the loop is
+    # spun for --spin-seconds before the W warm-up steps; nothing of it is timed.
+    if args.spin_seconds > 0:
+        t_spin = time.perf_counter()
+        base = 0
+        while time.perf_counter() - t_spin < args.spin_seconds:
+            run_steps(base, 512, main_pool)
+            base += 512
+        fence()
     if args.warmup:
         run_steps(0, args.warmup, main_pool)
     fence()
@@ -381,6 +403,7 @@ def main():
                                    "in rotation)" % POOL,
                        "images_per_step": world, "H": H, "W": W, "C": C, "O": O,
                        "pipeline_depth": depth,
+                       "untimed_spin_up_s": args.spin_seconds,
                        "host_overlap": "launch of step i queued before the read-back of step i - %d "
                                        "(mn_segment_launch / mn_segment_finish, %d contexts in rotation on "
                                        "ONE compute stream: the sweeps of different images run one after the "
