@@ -282,7 +282,8 @@ def main():
                      "last_mask_equals_serial_run": bool(torch.equal(pm, mask)),
                      "how": "mergenet_amd.segmenter.MergerPool: %d contexts, host threads and HIP streams; "
                             "same images; kernels of concurrent images share the chip, so per-kernel "
-                            "durations roughly double while images per second rise" % PIPELINED_DEPTH}
+                            "durations roughly double (round 1's way of keeping the chip busy; since round 2 "
+                            "the ring of contexts on one stream above is faster)" % PIPELINED_DEPTH}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -439,13 +440,12 @@ def main():
         if general is not None:
             sc_ms = general["ms_class_pass"] + general["ms_edge_pass"]
             sc = (C + O) * plane_bytes / (sc_ms * 1e-3) / 1e9
-            sc_traffic = None
-            old = os.path.join(ROOT, "profiles", "r01_pmc_score_1024x2048.json")
-            if os.path.exists(old):
-                with open(old) as fh:
-                    sc_traffic = json.load(fh).get("affinity_scoring_pass_hbm_bytes_per_launch")
+            from_cores = general["ms_class_pass"] == 0      # the general rounds start from the cores: same sweep
+            sc_traffic = pmc.get("mn_cc_sign") if from_cores else None
             out["scoring_pass_general_path"] = {
-                "bound": "hbm", "kernel": "mn_class_pass + mn_edge_pass_fast<10,true> (mode rounds)",
+                "bound": "hbm",
+                "kernel": "mn_cc_sign (mode rounds: the same single sweep, then cores, clusters, rounds, finisher)"
+                          if from_cores else "mn_class_pass + mn_edge_pass_fast (mode rounds from single pixels)",
                 "achieved": round(sc, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(sc / HBM_PEAK_GBS, 4), "traffic": sc_traffic,
                 "algorithmic_bytes": (C + O) * plane_bytes, "avg_launch_ms": round(sc_ms, 5),
