@@ -637,7 +637,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
       hipLaunchKernelGGL(mn_class_pass, dim3(blocks), dim3(256), 0, st, P, c->cls0);
     }
     unsigned* bits2 = reinterpret_cast<unsigned*>(c->label);      // free until the finisher
-    // short offsets: within 3 pixels (the unit offsets are among them); bit 6: all offsets count as short
+    // short offsets: both components within core_radius pixels (default 6; < 0: every offset is short)
     for (int k = 0; k < P.O; k++)
       if (c->core_radius < 0 || (abs(P.di[k]) <= c->core_radius && abs(P.dj[k]) <= c->core_radius)) kshort |= 1u << k;
     hipLaunchKernelGGL(mn_core_clean, dim3(grid_for(N, 256)), b, 0, st, P, (const unsigned*)c->cc_bits,
