@@ -1051,6 +1051,8 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       productive = 1;
       for (int w = 1; w < sub_r; w++)
         if (c->h_touch[64 + w]) productive = w + 1;
+      if (getenv("MN_TRACE_ROUNDS"))
+        fprintf(stderr, "round %d: R %d -> %d, sub-rounds used %d of %d\n", rounds, R, Rn, productive, sub_r);
       rounds++;
       const int selected = c->h_cnt->any_selected;
       RecList t = cur; cur = nxt; nxt = t;
