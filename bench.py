@@ -249,12 +249,20 @@ def main():
     # core clock).  A service that merges images all day runs at the sustained clocks, so the loop is
     # spun for --spin-seconds before the W warm-up steps; nothing of it is timed.
     if args.spin_seconds > 0:
-        t_spin = time.perf_counter()
-        base = 0
-        while time.perf_counter() - t_spin < args.spin_seconds:
-            run_steps(base, 512, main_pool)
-            base += 512
+        # (a step count every rank agrees on: the steps hold collectives when N > 1)
         fence()
+        t_probe = time.perf_counter()
+        run_steps(0, 32, main_pool)
+        fence()
+        per_step = (time.perf_counter() - t_probe) / 32
+        if world > 1:
+            t = torch.tensor([per_step], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            per_step = float(t.item())
+        spin_steps = int(min(1 << 16, max(0, args.spin_seconds / max(per_step, 1e-6))))
+        if spin_steps:
+            run_steps(32, spin_steps, main_pool)
+            fence()
     if args.warmup:
         run_steps(0, args.warmup, main_pool)
     fence()
