@@ -725,3 +725,17 @@ def test_core_with_a_non_positive_edge_inside_falls_apart(oracle):
         assert st["status"] == 0 and st["cores_condemned"] == (1 if bridge else 0), st
         assert mask.min() >= 0 and mask.max() == len(classes) == st["num_instances"]
         assert labels.agreement(mask, ref.mask) >= 0.97 * mask.size, (bridge, st, len(ref.object_class))
+
+
+@pytest.mark.parametrize("name,floor", [("cseg_blur_64x128_r2", 0.985), ("cseg_blur_64x128_r2_s8001", 0.985),
+                                        ("cseg_blur_256x512_r2", 0.995)])
+def test_blurred_maps_general_path_stays_close_to_the_reference(oracle, name, floor):
+    """Not equality (strict xfail above) but a floor under the approximation: the general path (cores of
+    radius 6, band 0.05, hand-over at 2048) finds the reference's instance count and agrees with its
+    partition on 99.0-99.7 % of the pixels of these vectors; a change that moves it further away --
+    cores from a radius of 3 lose an instance on the 64x128 vectors -- turns this red."""
+    g = gu.load(name)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS)
+    assert stats["mode_used"] == seg.MN_MODE_ROUNDS and stats["proof"] == 0
+    assert len(classes) == len(g["object_class"])
+    assert labels.agreement(mask, g["mask"]) >= floor * mask.size, stats
