@@ -739,3 +739,26 @@ def test_blurred_maps_general_path_stays_close_to_the_reference(oracle, name, fl
     assert stats["mode_used"] == seg.MN_MODE_ROUNDS and stats["proof"] == 0
     assert len(classes) == len(g["object_class"])
     assert labels.agreement(mask, g["mask"]) >= floor * mask.size, stats
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (50, 70), (61, 96), (64, 101), (97, 130)])
+@pytest.mark.parametrize("flags", [0, 8])
+def test_general_path_on_odd_shapes_equals_oracle(oracle, shape, flags):
+    """Widths and pixel counts that are not multiples of 4 (the one-pixel-per-lane forms of the sweep,
+    the separate class sweep, tail lanes of every 4-pixel kernel), through the general path with
+    (flags 0) and without (flags 8) the cluster contraction: separable maps, so the reference's result
+    is expected exactly."""
+    H, W = shape
+    offs = synth.generate_offsets(12, 8)
+    for seed in (4100, 4101, 4102):
+        s = synth.synth_v1(H, W, 5, offs, seed, noise=0.2, num_instances=4)
+        ref = oracle.run_csegment(s.class_probs, s.sameness_probs, 5, offs, 0.0, 1.0, 0.03)
+        ctx = seg.HostContext(H, W, 5, len(offs))
+        try:
+            o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=flags)
+            mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
+        finally:
+            ctx.close()
+        assert st["status"] == 0
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (shape, seed, flags, st)
+        assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
