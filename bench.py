@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--replay", action="store_true",
                     help="fixed output buffers per context + hipGraph replay of the launches after the sweep "
                          "(debug_flags bit 5): less host time per image")
+    ap.add_argument("--exchange-batch", type=int, default=8,
+                    help="N > 1: this many steps' masks share one all-gather (fewer, larger collectives; every "
+                         "one of them completes inside the timed region)")
     ap.add_argument("--wire", default="runs", choices=["runs", "int16"],
                     help="wire format of the mask exchange for N > 1 (run-length change points | int16 map)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -174,7 +177,7 @@ def main():
     ring_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(max(1, args.streams) - 1)]
     from mergenet_amd.distributed import MaskExchange
     # the exchange of step i (int16 wire format, one all-gather) overlaps the merge of step i+1
-    ex = MaskExchange(H, W, dev, fmt=args.wire, merger=merger) if world > 1 else None
+    ex = MaskExchange(H, W, dev, fmt=args.wire, merger=merger, batch=args.exchange_batch) if world > 1 else None
 
     from collections import deque
 
@@ -430,6 +433,7 @@ def main():
                             "backend": (ex.backend if ex is not None else "none"),
                             "wire_format": (args.wire if world > 1 else None),
                             "wire_bytes_per_rank_per_step": (ex.bytes_per_rank if ex is not None else 0),
+                            "steps_per_collective": (ex.batch if ex is not None else None),
                             "exchange_wait_ms_per_step": round(exchange_wait_ms / max(1, args.steps), 5),
                             "delivered_data_checked": exchange_ok},
             "roofline": roofline,

@@ -117,6 +117,56 @@ def test_mask_exchange_async_world2_gloo(fmt):
     assert {k: v[0] for k, v in dict(out).items()} == {0: True, 1: True}
 
 
+def _exchange_batch_worker(rank, world, port, out, fmt):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, B = 5, 7, 3
+    ex = mnd.MaskExchange(H, W, torch.device("cpu"), depth=2, fmt=fmt, batch=B)
+    ok = True
+    handles = []
+
+    def check(step, handle):
+        good = True
+        masks, tabs, counts = ex.result(handle)
+        good &= ex.logprobs(handle).tolist() == [-7.25 * (r + 1) - step for r in range(world)]
+        for r in range(world):
+            kr = 1 + (r + step) % 3
+            good &= bool((masks[r].to(torch.int32) == _test_mask(H, W, r, step)).all())
+            good &= int(counts[r]) == kr and tabs[r, :kr].tolist() == [i + 3 * r + step for i in range(kr)]
+        return good
+
+    # 8 submits with batches of 3: collectives after submits 3 and 6, the last two flushed by result()
+    for step in range(8):
+        k = 1 + (rank + step) % 3
+        table = torch.full((H * W,), -1, dtype=torch.int32)
+        table[:k] = torch.arange(k, dtype=torch.int32) + 3 * rank + step
+        handles.append(ex.submit(_test_mask(H, W, rank, step), table, k, -7.25 * (rank + 1) - step))
+        if step % B == B - 1:                      # a batch has gone out: read all of it
+            for j in range(step - B + 1, step + 1):
+                ok &= check(j, handles[j])
+    ok &= handles == [0, 1, 2, 3, 4, 5, 0, 1]      # slot * B + position, two slots in rotation
+    ok &= check(7, handles[7]) and check(6, handles[6])    # partly filled batch: flushed on demand
+    # after a flush the next submit starts a new batch in the next slot
+    h = ex.submit(_test_mask(H, W, rank, 9), torch.full((H * W,), -1, dtype=torch.int32), 0, 0.0)
+    ok &= h == 3
+    ex.drain()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fmt", ["runs", "int16"])
+def test_mask_exchange_batched_world2_gloo(fmt):
+    """batch=3: three submits share one collective; a partly filled batch goes out when one of its
+    results is asked for; every delivered mask, table, count and log-likelihood is checked."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_batch_worker, args=(world, port, out, fmt), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def test_run_length_wire_round_trip_and_size():
     """pack_runs_cpu / unpack_runs_cpu (the CPU twins of mn_pack_runs_device / mn_unpack_runs_device):
     random piecewise-constant masks come back exactly; a mask with too many changes says so; at

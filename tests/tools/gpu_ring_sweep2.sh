@@ -1,7 +1,4 @@
-for r in "" "--replay" "" "--replay"; do
-    python bench.py --no-cpu-baseline --no-general-path --no-pipelined $r 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('replay [$r] %8.1f Mpixel/s  %.4f ms/step  sweep %.1f us' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'] * 1e3))
-"
+for b in 1 8; do
+MN_BENCH_REHEARSAL=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 203 --warmup 5 --no-cpu-baseline --spin-seconds 0.5 --exchange-batch $b 2>/dev/null | python tools/show_bench.py /dev/stdin | grep "value\|distributed\|id_match"
 done
+python -m pytest tests/test_gpu_prepare.py -q -m gpu 2>&1 | tail -2
