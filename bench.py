@@ -165,13 +165,14 @@ def main():
     main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                merge_logprob_bias=OPTS[2], mode=args.mode,
-                               debug_flags=2 if args.no_kernel_events else 0)
+                               debug_flags=(2 if args.no_kernel_events else 0) | int(os.environ.get("MN_BENCH_FLAGS", "0")))
     # HIP events are host work (~3.5 us to record, ~8 us to read): every timed step carries the pair
     # around the sweep (the roofline kernel); one step in EVENTS_EVERY carries all of them (the
     # per-phase report), so that the host does not become the bottleneck of the loop it measures
     opts_lean = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
                                     merge_logprob_bias=OPTS[2], mode=args.mode,
-                                    debug_flags=2 if args.no_kernel_events else (48 if args.replay else 16))
+                                    debug_flags=(2 if args.no_kernel_events else (48 if args.replay else 16))
+                                    | int(os.environ.get("MN_BENCH_FLAGS", "0")))
     ring_out = [(torch.empty((H, W), dtype=torch.int32, device=dev), torch.empty((H * W,), dtype=torch.int32, device=dev))
                 for _ in range(max(1, args.contexts))] if args.replay else None
     ring_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(max(1, args.streams) - 1)]
@@ -389,9 +390,10 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
                     "algorithmic_bytes": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_launch_ms"],
-                    "timing": "hipEvent pair on the launch stream around the kernel in EVERY timed step "
-                              "(includes the ~5 us dispatch gap; rocprofv3 kernel-only durations are in "
-                              "profiles/r02_bench_kernel_stats.csv); the other phases' events are recorded "
+                    "timing": "hipEvent pair attached to the kernel's own dispatch on the launch stream "
+                              "(hipExtLaunchKernel start/stop events) in EVERY timed step; rocprofv3 "
+                              "durations of the same loop are in profiles/r02_bench_kernel_stats.csv; "
+                              "the other phases' events are recorded "
                               "in one step of %d, because events are host work and the host must not "
                               "become the bottleneck of the loop" % EVENTS_EVERY,
                     "why_this_kernel": "the one HBM-streaming kernel of the timed path: it reads every input "

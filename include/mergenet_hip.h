@@ -93,7 +93,10 @@ typedef struct mn_options {
                                   bit 4): replay -- when mn_segment_launch is called again with the
                                   same buffers, shape, options and stream, the launches after the
                                   sweep are recorded into two hipGraphs (second call) and replayed
-                                  (from the third): a loop over images through fixed buffers        */
+                                  (from the third): a loop over images through fixed buffers; bit 7:
+                                  time the sweep with an event packet before and behind it instead
+                                  of start/stop events on its own dispatch (round 2's first form:
+                                  measures dispatch gap + kernel)                                  */
   int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
                                   order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
                                   has at most exact_limit_proof initial records, else the call returns

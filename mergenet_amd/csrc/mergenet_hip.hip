@@ -4,6 +4,7 @@
 // -ffp-contract=off).  The entry points and the reference interfaces they replace are
 // documented in include/mergenet_hip.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -63,6 +64,7 @@ struct mn_context {
   int fin_lds_ready, tail_lds_ready;
   int* wire_counts;       // block counts + total of mn_pack_runs_device (apart from the image's own scratch)
   int core_radius;        // short-offset radius of the cores (mn_options::core_radius resolved)
+  int ext_events;         // the sweep carries its own start/stop events (hipExtLaunchKernel): no event packets around it
   int cores_used;         // the last attempt ran the general rounds from the cores (mn_core_clean)
   int cc_clean;           // 1: counters and the speculative record table were cleared at the end of the last image
   HashTab T;
@@ -466,7 +468,8 @@ static int run_phase_a(mn_context* c, const ImgParams& P, hipStream_t st, bool e
   fills->launch(st);
   if (components) {
     // one event for three timestamps: elapsed(ev[0], ev[0]) = 0 for the phases this mode does not have
-    MN_HIP(hipEventRecord(c->ev[0], st));
+    // (with ext_events the sweep's own dispatch sets it)
+    if (!c->ext_events) MN_HIP(hipEventRecord(c->ev[0], st));
     return MN_OK;
   }
   hipLaunchKernelGGL(mn_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, N, c->osize,
@@ -579,9 +582,18 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
     CO.gsum = reinterpret_cast<int*>(c->lpsum);     // (the summed class log-probs are written later, at roots only)
     CO.gstride = (size_t)P.N;
     const bool plain = !P.clip && P.sdb == 0.0f;
+    // Timed: the dispatch itself carries the two events (hipExtLaunchKernel: start and stop time of THIS
+    // kernel), instead of an event packet in front of it and one behind -- each of those cost a ~6 us
+    // dispatch gap on the stream, and the pair measured gap + kernel (54 us where rocprofv3 saw 46).
 #define MN_LAUNCH_SIGN(PLAINV, CLSV)                                                                    \
-    hipLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, \
-                       c->cc_negcnt, c->scalars + 6, c->partial, CO)
+    do {                                                                                                \
+      if (c->ext_events)                                                                                \
+        hipExtLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, c->ev[0], c->ev[10], 0, \
+                              P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt, c->scalars + 6, c->partial, CO); \
+      else                                                                                              \
+        hipLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, \
+                           c->cc_negcnt, c->scalars + 6, c->partial, CO);                               \
+    } while (0)
     if (plain && cls) MN_LAUNCH_SIGN(true, true);
     else if (plain) MN_LAUNCH_SIGN(true, false);
     else if (cls) MN_LAUNCH_SIGN(false, true);
@@ -627,7 +639,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   const bool fused_cls = four && (N & 3) == 0;
   if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
-  if (!few_events) MN_HIP(hipEventRecord(c->ev[10], st));
+  if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
   const unsigned* lbits = c->cc_bits;
   unsigned kshort = 0u;
@@ -840,6 +852,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
   c->debug_flags = opts->debug_flags;
+  c->ext_events = !(opts->debug_flags & 2) && !(opts->debug_flags & 128);
   c->core_radius = opts->core_radius != 0 ? opts->core_radius : MN_DEFAULT_CORE_RADIUS;
   const int N = P.N;
   const long long R0 = count_records(W, H, offset_dim, offset_list);
@@ -1244,8 +1257,9 @@ extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int c
     ImgParams P;
     fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, &q.opts);
     c->debug_flags = q.opts.debug_flags;
+    c->ext_events = !(q.opts.debug_flags & 2) && !(q.opts.debug_flags & 128);
     c->cores_used = 0;
-    const bool timed = !(q.opts.debug_flags & 2);
+    const bool timed = !(q.opts.debug_flags & 2) && !c->ext_events;
     if (timed) MN_HIP(hipEventRecord(c->ev[0], st));
     launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist,
                     (unsigned)((size_t)MN_CC_SIGN_THREADS * 4 * (size_t)P.O), true);

@@ -1,4 +1,8 @@
-for b in 1 8; do
-MN_BENCH_REHEARSAL=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 203 --warmup 5 --no-cpu-baseline --spin-seconds 0.5 --exchange-batch $b 2>/dev/null | python tools/show_bench.py /dev/stdin | grep "value\|distributed\|id_match"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_phase_a.py -q -m gpu -x 2>&1 | tail -2
+for f in 0 128 0 128; do
+    MN_BENCH_FLAGS=$f python bench.py --no-cpu-baseline --no-general-path --no-pipelined 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('extra flags $f %8.1f Mpixel/s  %.4f ms/step  sweep by events %.1f us frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'] * 1e3, d['roofline']['frac']))
+"
 done
-python -m pytest tests/test_gpu_prepare.py -q -m gpu 2>&1 | tail -2
