@@ -249,7 +249,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->bg_key, 1));
   for (int i = 0; i < 12; i++) MN_HIP(hipEventCreate(&c->ev[i]));
   MN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  MN_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  MN_HIP(hipEventCreate(&c->ev_fork));            // (timing enabled: it can be the stop event of a dispatch)
   {
     // The tail of an image runs beside the NEXT images' sweeps and should not take compute units from
     // them: its stream gets the lowest priority the device offers (sweep 53 instead of 57-60 us by
@@ -573,7 +573,8 @@ static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, 
 // and the verdict is read by the caller at the end.
 template <int PX>
 static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
-                         u64* neg_list, unsigned sub_cap, bool cls = false, const unsigned* hook_bits = nullptr) {
+                         u64* neg_list, unsigned sub_cap, bool cls = false, const unsigned* hook_bits = nullptr,
+                         hipEvent_t hook_done = nullptr) {
   const int N = P.N, ngroups = (N + PX - 1) / PX;
   if (!hook) {
     const dim3 g(grid_for(ngroups, MN_CC_SIGN_THREADS)), b(MN_CC_SIGN_THREADS);
@@ -601,8 +602,12 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
 #undef MN_LAUNCH_SIGN
   } else {
     const dim3 gx(8 * ((grid_for(ngroups, 256) + 7) / 8));
-    hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, hook_bits ? hook_bits : (const unsigned*)c->cc_bits,
-                       c->parent, kmask);
+    if (hook_done)                 // (its completion is the fork point of the image: no event packet behind it)
+      hipExtLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, nullptr, hook_done, 0, P,
+                            hook_bits ? hook_bits : (const unsigned*)c->cc_bits, c->parent, kmask);
+    else
+      hipLaunchKernelGGL(mn_cc_hook<PX>, gx, dim3(256), 0, st, P, hook_bits ? hook_bits : (const unsigned*)c->cc_bits,
+                         c->parent, kmask);
   }
 }
 
@@ -675,9 +680,11 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (kv >= 0) kmask &= ~(1u << kv);
   }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
+  // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
+  const bool fork_by_hook = fork_before_sums && kmask && c->ext_events && !c->replay.capturing;
   if (kmask) {
-    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits);
-    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits);
+    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
+    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
   }
   if (c->replay.capturing) {
     MN_HIP(hipStreamEndCapture(c->replay.cap, &c->replay.gA));
@@ -696,7 +703,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
     // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
     // for the side stream; nothing of this image is left on the caller's stream after this point.
-    MN_HIP(hipEventRecord(c->ev_fork, st));
+    if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
     MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     st = c->side;
     if (c->replay.capturing) {     // everything from here to the end of the image goes into graph B
