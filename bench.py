@@ -9,8 +9,8 @@ One "step" = one pass of the hot path over one batch of synthetic input: every r
 1024x2048 Cityscapes-shape image (C=9 classes, O=10 log-spiral offsets, options 0/1/0.03 of
 egs/cityscape/local/segment.py:134-136) whose probability maps are already resident in HBM, and --
 for N > 1 -- the final masks and class tables are all-gathered over RCCL (the only exchange step
-of the path; images are independent; int16 wire format, the gather of step i overlaps the merge
-of step i+1, all of them complete inside the timed region).  Weak scaling: per-GPU work is fixed.  Each rank cycles
+of the path; images are independent; run-length wire format, 8 steps per collective, the gathers overlap
+the merges of the following steps, all of them complete inside the timed region).  Weak scaling: per-GPU work is fixed.  Each rank cycles
 through POOL different images (636 MB of maps, more than the 256 MiB Infinity Cache), so a step
 reads its maps from HBM and not from a cache warmed by the previous step.
 
