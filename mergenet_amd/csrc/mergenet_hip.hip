@@ -671,7 +671,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     MN_HIP(hipStreamBeginCapture(c->replay.cap, hipStreamCaptureModeThreadLocal));
     st = c->replay.cap;
   }
-  hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(1024), 0, st, P, lbits, c->parent, kh, kv, dv,
+  hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(MN_CC_TILE_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv,
                      c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
   if (kh >= 0 || kv >= 0) {

@@ -324,11 +324,13 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
 //     pair of roots in a wave);
 //  3. the flattened labels go to `parent` as pixel ids.  Local order (row, column) is the global
 //     pixel order, so "larger root under smaller" keeps holding across stages.
-#define MN_CC_TILE_ROWS 16
+#ifndef MN_CC_TILE_ROWS
+#define MN_CC_TILE_ROWS 16    /* rows of a labelling tile (x 64 columns = the block of mn_cc_tiles) */
+#endif
 //  4. every pixel's component size starts at 0 and the accumulators of the TILE roots are cleared
 //     (class sums -- only the roots' slots of the C planes are ever used -- and class range): the
 //     stages that follow only remove roots, so the final roots are among them.
-__global__ __launch_bounds__(1024) void mn_cc_tiles(ImgParams P, const unsigned* __restrict__ bits,
+__global__ __launch_bounds__(MN_CC_TILE_ROWS * 64) void mn_cc_tiles(ImgParams P, const unsigned* __restrict__ bits,
                                                     int* __restrict__ parent, int kh, int kv, int dv,
                                                     int* __restrict__ osize, i64* __restrict__ lp_acc,
                                                     int* __restrict__ clsmin, int* __restrict__ clsmax,
