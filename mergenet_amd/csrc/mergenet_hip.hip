@@ -21,6 +21,7 @@
 #include "mn_kernels_cc.h"
 #include "mn_kernels_tail.h"
 #include "mn_kernels_oc.h"
+#include "mn_kernels_exact.h"
 
 // Counters | 16 int scalars | 4 doubles, each part 16-byte aligned
 // scalars: [0] edge violations [1] instances [2] objects [3] class violations [4] record violations
@@ -133,6 +134,15 @@ struct mn_context {
   hipEvent_t ev_fork;
   ImgParams last_params;  // of the most recent mn_segment_device call (for mn_instance_scores_device)
   int last_valid;
+  // workspace of the exact engine (mn_kernels_exact.h): allocated on first use, for the largest
+  // image seen so far
+  struct XWork {
+    XState X;
+    size_t n_pix, n_rec, n_cls_floats, hcap, arena_cap, leaf_cap;   // capacities of what is allocated
+    size_t bytes;
+    XCtl* h_ctl;                  // pinned
+    int lds_ready;
+  } xw;
   // staging for the host-pointer entry points
   float *d_class, *d_same;
   int *d_mask, *d_objcls, *d_part;
@@ -151,6 +161,76 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
   const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
   c->bytes += b;
   return hipMalloc(reinterpret_cast<void**>(p), b);
+}
+
+// ---- exact engine: workspace ------------------------------------------------------------------------
+static void x_free(mn_context* c) {
+  XState& X = c->xw.X;
+  void* dev[] = {X.rkey, X.roml, X.leaf, X.rslot, X.hkey, X.hval, X.lp, X.aptr, X.alen, X.acap, X.arena, X.l1g, X.ctl};
+  for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
+    if (dev[i]) (void)hipFree(dev[i]);
+  if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
+  c->bytes -= c->xw.bytes;
+  memset(&c->xw, 0, sizeof(c->xw));
+}
+
+template <typename T>
+static hipError_t x_alloc(mn_context* c, T** p, size_t n) {
+  const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
+  c->xw.bytes += b;
+  c->bytes += b;
+  return hipMalloc(reinterpret_cast<void**>(p), b);
+}
+
+// Sizes the workspace for an image of N pixels, O offsets, C classes.  Per pixel (C = 9, O = 10):
+// records 20 B x O, pair table ~38 B x O, class vectors 4 B x C, adjacency arena 4 B x 384:
+// ~2.2 KB, 4.6 GB for 1024 x 2048 (of 288 GB).
+static int x_ensure(mn_context* c, int N, int O, int C) {
+  mn_context::XWork& w = c->xw;
+  const size_t NL = (size_t)N * O;
+  if (NL >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
+  size_t B = 256;
+  while ((NL + B - 1) / B > MN_X_MAXBLOCKS) B <<= 1;
+  const size_t NB = (NL + B - 1) / B;
+  const size_t leaf_cap = NB * B;
+  const size_t hcap = next_pow2(2 * NL + 1024);
+  int cap0 = 64;
+  while (cap0 < 4 * O) cap0 <<= 1;
+  const size_t arena_cap = (size_t)N * cap0 + (size_t)N * 320 + 65536;
+  if (arena_cap >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
+  if (w.n_pix < (size_t)N || w.n_rec < NL || w.n_cls_floats < (size_t)N * C || w.hcap < hcap ||
+      w.arena_cap < arena_cap || w.leaf_cap < leaf_cap) {
+    x_free(c);
+    XState& X = w.X;
+    MN_HIP(x_alloc(c, &X.rkey, NL));
+    MN_HIP(x_alloc(c, &X.roml, NL));
+    MN_HIP(x_alloc(c, &X.leaf, leaf_cap));
+    MN_HIP(x_alloc(c, &X.rslot, NL));
+    MN_HIP(x_alloc(c, &X.hkey, hcap));
+    MN_HIP(x_alloc(c, &X.hval, hcap));
+    MN_HIP(x_alloc(c, &X.lp, (size_t)N * C));
+    MN_HIP(x_alloc(c, &X.aptr, (size_t)N));
+    MN_HIP(x_alloc(c, &X.alen, (size_t)N));
+    MN_HIP(x_alloc(c, &X.acap, (size_t)N));
+    MN_HIP(x_alloc(c, &X.arena, arena_cap));
+    MN_HIP(x_alloc(c, &X.l1g, (size_t)MN_X_MAXBLOCKS));
+    MN_HIP(x_alloc(c, &X.ctl, 1));
+    MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), sizeof(XCtl)));
+    w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = hcap; w.arena_cap = arena_cap;
+    w.leaf_cap = leaf_cap;
+  }
+  XState& X = w.X;
+  X.hmask = (unsigned)(hcap - 1);
+  X.arena_cap = arena_cap;
+  X.Blog = 0;
+  while (((size_t)1 << X.Blog) < B) X.Blog++;
+  X.NB = (int)NB;
+  X.NBpad = (int)((NB + 63) / 64 * 64);
+  X.NG = X.NBpad / 64;
+  X.NL = (unsigned)NL;
+  X.cap0 = cap0;
+  X.osize = c->osize; X.ocls = c->ocls; X.parent = c->parent;
+  return MN_OK;
 }
 
 extern "C" void mn_default_options(mn_options* o) {
@@ -306,6 +386,7 @@ extern "C" void mn_destroy(mn_context* c) {
                  c->bg_key, c->gmax, c->touch, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
+  x_free(c);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   if (c->h_touch) (void)hipHostFree(c->h_touch);
   for (int i = 0; i < 12; i++)
@@ -770,6 +851,80 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   return 0;
 }
 
+// ---- exact engine: set-up kernels, the loop, hand-over to the output stage ------------------------
+// The loop kernel is ONE wavefront that runs until the queue is empty; it comes back early when its
+// step budget is used up (MN_X_BUDGET: block maxima are rebuilt and it is launched again) or when the
+// adjacency arena is full.  `ev[1]`, `ev[2]` bracket the two set-up kernels (class terms / records).
+static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
+  int rc = x_ensure(c, P.N, P.O, P.C);
+  if (rc != MN_OK) return rc;
+  mn_context::XWork& w = c->xw;
+  XState& X = w.X;
+  const size_t N = (size_t)P.N;
+  MN_HIP(hipMemsetAsync(X.hkey, 0xFF, ((size_t)X.hmask + 1) * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(X.arena, 0xFF, N * (size_t)X.cap0 * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.leaf, 0, ((size_t)X.NB << X.Blog) * sizeof(unsigned), st));
+  memset(w.h_ctl, 0, sizeof(XCtl));
+  w.h_ctl->bump = (unsigned long long)N * (unsigned long long)X.cap0;
+  MN_HIP(hipMemcpyAsync(X.ctl, w.h_ctl, sizeof(XCtl), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(mn_x_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->cls0);
+  MN_HIP(hipEventRecord(c->ev[1], st));
+  hipLaunchKernelGGL(mn_x_init_records, dim3(grid_for((size_t)X.NL, 256)), dim3(256), 0, st, P, X);
+  MN_HIP(hipEventRecord(c->ev[2], st));
+  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 64;
+  if (!w.lds_ready) {
+    MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    w.lds_ready = 1;
+  }
+  // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per record
+  // (plus slack) is the hard stop of a run, whatever the input
+  const long long max_total = 8LL * (long long)X.NL + 65536;
+  long long per_launch = 1LL << 24;                  // steps per launch (MN_X_BUDGET: tests of the relaunch)
+  if (const char* e = getenv("MN_X_BUDGET")) { const long long v = atoll(e); if (v > 0) per_launch = v; }
+  const long long max_launches = 1 << 20;
+  for (long long it = 0; it < max_launches; it++) {
+    const long long left = max_total - w.h_ctl->steps;
+    if (left <= 0) {
+      fprintf(stderr, "mergenet_hip: exact engine exceeded %lld steps\n", max_total);
+      return MN_ERR_INTERNAL;
+    }
+    const long long budget = left < per_launch ? left : per_launch;
+    hipLaunchKernelGGL(mn_x_build_l1, dim3(X.NB), dim3(64), 0, st, X);
+    hipLaunchKernelGGL(mn_x_run, dim3(1), dim3(64), lds, st, P, X, budget);
+    MN_HIP(hipGetLastError());
+    MN_HIP(hipMemcpyAsync(w.h_ctl, X.ctl, sizeof(XCtl), hipMemcpyDeviceToHost, st));
+    MN_HIP(hipStreamSynchronize(st));
+    const int status = w.h_ctl->status;
+    if (status == MN_X_DONE) break;
+    if (status == MN_X_BUDGET) continue;
+    if (status == MN_X_ARENA_FULL || status == MN_X_HASH_FULL) {
+      fprintf(stderr, "mergenet_hip: exact engine out of %s after %lld steps\n",
+              status == MN_X_ARENA_FULL ? "adjacency arena" : "pair table", w.h_ctl->steps);
+      return MN_ERR_CAPACITY;
+    }
+    fprintf(stderr, "mergenet_hip: exact engine stopped with status %d after %lld steps\n", status, w.h_ctl->steps);
+    return MN_ERR_INTERNAL;
+  }
+  if (w.h_ctl->status != MN_X_DONE) return MN_ERR_INTERNAL;
+  if (getenv("MN_TRACE_EXACT"))
+    fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld probes %lld arena %llu of %llu\n",
+            w.h_ctl->steps, w.h_ctl->merges, w.h_ctl->rescans, w.h_ctl->reallocs, w.h_ctl->folded,
+            w.h_ctl->adopted, w.h_ctl->probes, w.h_ctl->bump, X.arena_cap);
+  // what the output stage reads: class sums of the survivors (plane-major), step counters
+  hipLaunchKernelGGL(mn_x_export_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->lpsum, c->lpvalid);
+  const long long steps = w.h_ctl->steps, merges = w.h_ctl->merges;
+  Counters hc;
+  memset(&hc, 0, sizeof(hc));
+  hc.finisher_steps = (int)(steps > 0x7FFFFFFF ? 0x7FFFFFFF : steps);
+  hc.finisher_merges = (int)merges;
+  hc.n_merged = (int)merges;
+  *c->h_cnt = hc;
+  MN_HIP(hipMemcpyAsync(c->cnt, c->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, st));
+  MN_HIP(hipGetLastError());
+  return MN_OK;
+}
+
 // Internal verdicts of a speculative attempt (never returned to the caller).
 #define MN_RETRY_ROUNDS 1001   /* not sign-separable: redo with the rounds            */
 #define MN_RETRY_WAIT 1002     /* more records than the finisher takes: redo, waiting for the count */
@@ -884,6 +1039,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
         (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;
+  // the sequential order at any size: the exact engine (C++ variant; the Python variant's float64
+  // state stays with the small-list finisher; debug_flags bit 8 keeps the old engine for comparison)
+  const bool xengine = mode == MN_MODE_EXACT && opts->variant == MN_VARIANT_CSEGMENT && !(opts->debug_flags & 256);
   ObjState S = obj_state(c);
   // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
   // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph
@@ -934,7 +1092,13 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // ---------------- phase A ----------------
   bool cores = mode == MN_MODE_ROUNDS && cores_ok;
   if (cores) fills.add(c->touch, 64 * sizeof(unsigned), 0);        // (edges outside the cores: mn_core_bits)
-  rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS && !cores, &fills, mode == MN_MODE_COMPONENTS || cores);
+  if (xengine) {
+    fills.launch(st);
+    MN_HIP(hipEventRecord(c->ev[0], st));
+    rc = run_exact_engine(c, P, st);
+  } else {
+    rc = run_phase_a(c, P, st, mode == MN_MODE_ROUNDS && !cores, &fills, mode == MN_MODE_COMPONENTS || cores);
+  }
   if (rc != MN_OK) return rc;
   if (mode == MN_MODE_COMPONENTS) {
     rc = run_components(c, P, st, !speculate, !speculate, !fused_tail, fused_tail);
@@ -976,7 +1140,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                        (const int*)c->mate, c->cnt);
     rounds = 1;
   }
-  if (mode == MN_MODE_COMPONENTS) {
+  if (xengine) {
+    R = 0;
+  } else if (mode == MN_MODE_COMPONENTS) {
     // run_components already compacted the table into the list; speculating, the count is still
     // on the device: launches below are sized for the most the finisher takes
     R = speculate ? finish_limit : c->h_cnt->n_records;
@@ -1099,7 +1265,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   }
   const bool want_cert = opts->compute_logprob != 0;
   // sequential lazy-greedy on what is left (the whole problem in exact mode)
-  if (fused_tail) {
+  if (xengine) {
+    // (the engine has run to the end of the queue)
+  } else if (fused_tail) {
     if (!c->tail_lds_ready) {
       MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_cc_tail),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, MN_FIN2_MAXR * 12));
@@ -1188,6 +1356,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
                          (const unsigned char*)c->cls0, (const int*)c->root, c->partial, c->scalars);
     hipLaunchKernelGGL(mn_verify_reduce, dim3(1), dim3(256), 0, st, vb, (const double*)c->partial,
                        P.omf, c->lp_out);
+    if (xengine)
+      hipLaunchKernelGGL(mn_x_verify_records, dim3(grid_for((size_t)c->xw.X.NL, 256)), dim3(256), 0, st, P,
+                         c->xw.X, c->scalars);
     if (R > 0)
       hipLaunchKernelGGL(mn_verify_records, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R,
                          c->scalars, speculate ? (const int*)&c->cnt->n_records : (const int*)nullptr);

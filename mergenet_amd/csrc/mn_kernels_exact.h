@@ -1,0 +1,615 @@
+// mn_kernels_exact.h -- the reference's sequential order itself, at any image size.
+//
+// Restates RunSegmentation + Merge (utils/csegment/segment.cc:539-573, 602-727) with the reference's
+// own float32 arithmetic (segment.cc:5-46, 107-150): one step = pop the record with the largest
+// stored priority, re-score it, merge when the fresh value equals the stored one, otherwise store the
+// fresh value; a merge folds / re-keys ONLY the absorbed object's records and re-scores only those
+// (:650-707).  A queue entry whose priority differs from the record's is skipped by the reference
+// (:554), so its queue is equivalent to "the stored priority of every live record, if >= 0".
+//
+// What makes a step cost a few global round trips whatever the image size:
+//   * queue   = one 32-bit sortable word per record in HBM (`leaf`), blocks of 2^Blog leaves whose
+//               maxima (word, record) live in LDS (`l1`, up to 16 K blocks) under a second LDS level
+//               (`l2`, one entry per 64 blocks): pop = 4 LDS reads per lane + a wave reduction; an
+//               update touches the leaf, the block maximum and its group; a block is re-read from HBM
+//               only when its maximum was lowered or removed (the popped block always: read beside
+//               the step's other loads)
+//   * records = flat arrays indexed by record id = pixel * O + offset index (the reference's creation
+//               order, segment.cc:209-231): key (object pair), float32 log-odds sum, hash slot
+//   * pair -> record: one open-addressing table over (min id, max id) keys (the reference keeps a
+//               hash map per object, segment.h:136): fold look-ups of a merge run in parallel lanes
+//   * adjacency = one contiguous array of record ids per object in an arena; a merge walks ONLY the
+//               absorbed object's array (64 records per pass) and appends the re-keyed records to the
+//               survivor's (doubling reallocation, dead entries dropped on the way)
+// One wavefront runs the loop: no barriers, cross-lane traffic by ballot / shuffle / LDS.  Several
+// images can run side by side on different CUs (one context each).
+//
+// Ties between bit-equal stored priorities go to the lowest record id (the creation order of the
+// reference's records); the reference's order among equal keys comes from std::priority_queue's heap
+// mechanics, which this does not emulate -- on every reference vector of tests/golden that depends on
+// ties (cseg_synth_32x64_n60 among them) the two agree.
+#pragma once
+
+#include "mn_device.h"
+
+#define MN_X_INVALID 0xFFFFFFFFu
+#define MN_X_HEMPTY 0xFFFFFFFFFFFFFFFFull
+#define MN_X_HTOMB 0xFFFFFFFFFFFFFFFEull
+#define MN_X_DIRTY 0xFFFFFFFFFFFFFFFFull
+#define MN_X_MAXBLOCKS 16384
+
+enum { MN_X_RUNNING = 0, MN_X_DONE = 1, MN_X_BUDGET = 2, MN_X_ARENA_FULL = 3, MN_X_HASH_FULL = 4 };
+
+struct XCtl {
+  int status;                 // MN_X_*; < 0: mn_status error
+  int pad;
+  long long steps, merges, rescans, reallocs, folded, adopted, probes;
+  unsigned long long bump;    // next free arena entry
+};
+
+struct XState {
+  // records, indexed by record id (pixel * O + k)
+  u64* rkey;                  // (lower object id << 32) | higher; MN_EMPTY = dead / never existed
+  float* roml;                // AdjacencyRecord::obj_merge_logprob (float32, segment.cc:36, 690)
+  unsigned* leaf;             // queue word of the stored priority: 0 = not queued
+  unsigned* rslot;            // slot of the record's key in the pair table
+  // pair table
+  u64* hkey;
+  unsigned* hval;
+  unsigned hmask;
+  // objects
+  float* lp;                  // [N][C] Object::class_logprobs (float32 sums, segment.cc:640)
+  int* osize;
+  unsigned char* ocls;
+  int* parent;
+  unsigned* aptr;             // adjacency array: first arena entry
+  int* alen;                  //                  entries in use (dead ones included)
+  int* acap;                  //                  entries owned
+  unsigned* arena;
+  unsigned long long arena_cap;
+  // queue
+  u64* l1g;                   // block maxima in HBM (built by mn_x_build_l1, loaded into LDS)
+  int Blog, NB, NBpad, NG;
+  unsigned NL;                // record ids in use (N * O)
+  int cap0;                   // arena entries every pixel starts with
+  XCtl* ctl;
+};
+
+// ---- glibc's logf, bit for bit -------------------------------------------------------------------
+// The reference calls log(float) = logf for the class and sameness terms (segment.h:296, segment.cc:
+// 35); its float32 decisions depend on the exact values.  glibc 2.35 (the image's libm, and the
+// published algorithm of sysdeps/ieee754/flt-32/e_logf.c) evaluates, in double precision,
+//   log x = log1p(z / c - 1) + log c + k ln 2,  16-entry table of (1/c, log c), cubic in r = z/c - 1.
+// Restated here with the operation order of the FMA variant x86-64 dispatches to; checked against
+// the host's logf on all 2.13e9 positive normal floats (tests/test_ref_logf.py runs a sample).
+// Inputs are clipped to [2^-23, 1 - 2^-23] (c_segment.pyx:53-55): no zero, subnormal, inf or NaN.
+__device__ __forceinline__ float mn_ref_logf(float x) {
+  const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+      {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2}, {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+      {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+      {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1.0000000000000p+0, 0x0.0p+0},
+      {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
+      {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  const unsigned ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  const unsigned tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const int k = (int)tmp >> 23;
+  const unsigned iz = ix - (tmp & 0xff800000u);
+  const double z = (double)__uint_as_float(iz);
+  const double invc = T[i][0], logc = T[i][1];
+  const double y0 = fma((double)k, 0x1.62e42fefa39efp-1, logc);
+  const double r = fma(z, invc, -1.0);
+  double y = fma(r, 0x1.5575b0be00b6ap-2, -0x1.ffffef20a4123p-2);
+  const double r2 = r * r;
+  const double t = r + y0;
+  y = fma(r2, -0x1.00ea348b88334p-2, y);
+  return (float)fma(r2, y, t);
+}
+
+// differentness_logprob = log(1.0 - same_prob): a double log rounded to float (segment.cc:34)
+__device__ __forceinline__ float mn_ref_log1m(float v) { return (float)log(1.0 - (double)v); }
+
+// same_different_bias applied on load (segment.cc:183-195: float logf, double log, expf, double division)
+__device__ __forceinline__ float mn_ref_same_value(const ImgParams& P, float v) {
+  if (P.clip) v = mn_clip(v);
+  if (P.sdb != 0.0f) {
+    const float logit = (float)(((double)mn_ref_logf(v) - log(1.0 - (double)v)) + (double)P.sdb);
+    v = (float)(1.0 / (1.0 + (double)expf(-logit)));
+  }
+  return v;
+}
+
+__device__ __forceinline__ unsigned mn_x_word(float st) {
+  return (st >= 0.0f) ? (((st == 0.0f) ? 0u : __float_as_uint(st)) + 1u) : 0u;
+}
+__device__ __forceinline__ u64 mn_x_pack(unsigned w, unsigned rid) {
+  return w ? (((u64)w << 32) | (u64)(0xFFFFFFFFu - rid)) : 0ull;
+}
+__device__ __forceinline__ unsigned mn_x_rid(u64 e) { return 0xFFFFFFFFu - (unsigned)e; }
+
+__device__ __forceinline__ u64 mn_x_shfl_xor(u64 v, int off) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off);
+  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 mn_x_wave_max(u64 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const u64 o = mn_x_shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// priority of the record (a, b), a < b by id, by ONE lane (ComputeClassDeltaLogprob +
+// UpdateMergePriority, segment.cc:107-150): la / lb = class log-prob vectors of a / b
+__device__ __forceinline__ float mn_x_score1(const ImgParams& P, const float* la, const float* lb,
+                                             int ca, int cb, int na, int nb, float S, int* mc) {
+  float cdl = 0.0f;
+  int m = ca;
+  if (ca != cb) {
+    // sixteen classes of both vectors in flight at once (a loop of dependent loads would pay a
+    // memory round trip per class)
+    const float lca = la[ca], lcb = lb[cb];
+    float bestv = 0.0f;
+    m = 0;
+    for (int c0 = 0; c0 < P.C; c0 += 16) {
+      float va[16], vb[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        va[j] = 0.0f; vb[j] = 0.0f;
+        if (c0 + j < P.C) { va[j] = la[c0 + j]; vb[j] = lb[c0 + j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (c0 + j < P.C) {
+          const float v = va[j] + vb[j];
+          if ((c0 + j) == 0 || v > bestv) { bestv = v; m = c0 + j; }
+        }
+      }
+    }
+    cdl = (bestv - lca) - lcb;
+  }
+  *mc = m;
+  const float den = (float)((unsigned long long)na + (unsigned long long)nb);
+  return (S * P.omf + cdl) / den + P.bias;
+}
+
+// The same priority for a record between the survivor of a merge (class vector `lpa` in LDS, class
+// `ca`, `na` pixels) and a third object (vector `l3` in HBM): the joint vector is symmetric, only the
+// order of the two subtractions follows the ids (a_first: the survivor has the lower id).
+__device__ __forceinline__ float mn_x_score_fold(const ImgParams& P, const float* lpa, const float* l3,
+                                                 int ca, int c3cls, int na, int n3, float S, bool a_first) {
+  float cdl = 0.0f;
+  if (ca != c3cls) {
+    const float la_c = lpa[ca], l3_c = l3[c3cls];
+    float bestv = 0.0f;
+    for (int c0 = 0; c0 < P.C; c0 += 16) {
+      float vb[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) vb[j] = (c0 + j < P.C) ? l3[c0 + j] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (c0 + j < P.C) {
+          const float v = a_first ? (lpa[c0 + j] + vb[j]) : (vb[j] + lpa[c0 + j]);
+          if ((c0 + j) == 0 || v > bestv) bestv = v;
+        }
+      }
+    }
+    cdl = a_first ? ((bestv - la_c) - l3_c) : ((bestv - l3_c) - la_c);
+  }
+  const float den = (float)((unsigned long long)na + (unsigned long long)n3);
+  return (S * P.omf + cdl) / den + P.bias;
+}
+
+// ---- set-up (parallel, whole chip) -----------------------------------------------------------------
+// Object::Object (segment.cc:5-21): lp[c] = logf(p_c), class = first maximum
+__global__ __launch_bounds__(256) void mn_x_init_objects(ImgParams P, XState X,
+                                                         unsigned char* __restrict__ cls0) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  float best = 0.0f;
+  int bc = 0;
+  for (int c = 0; c < P.C; c++) {
+    const float l = mn_ref_logf(mn_ld_class(P, c, p));
+    X.lp[(size_t)p * P.C + c] = l;
+    if (c == 0 || l > best) { best = l; bc = c; }
+  }
+  X.osize[p] = 1;
+  X.ocls[p] = (unsigned char)bc;
+  cls0[p] = (unsigned char)bc;
+  X.parent[p] = p;
+  X.aptr[p] = (unsigned)p * (unsigned)X.cap0;
+  X.alen[p] = 2 * P.O;
+  X.acap[p] = X.cap0;
+}
+
+// AdjacencyRecord ctor + the constructor's loop (segment.cc:24-46, 209-231): one lane per
+// (pixel, offset); records its key, log-odds, initial priority word, table slot and its two
+// adjacency entries (slot k of the source pixel, slot O + k of the target pixel)
+__global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)P.N * P.O) return;
+  const int p = (int)(gid / P.O), k = (int)(gid - (size_t)p * P.O);
+  const unsigned rid = (unsigned)gid;
+  const int r = p / P.W, c = p - r * P.W;
+  const int rr = r + P.di[k], cc = c + P.dj[k];
+  if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) {
+    X.rkey[rid] = MN_EMPTY;
+    X.leaf[rid] = 0u;
+    return;
+  }
+  const int q = rr * P.W + cc;
+  const float v = mn_ref_same_value(P, P.same[(size_t)k * P.N + p]);
+  const float diff = mn_ref_log1m(v);
+  const float same = mn_ref_logf(v);
+  const float oml = same - diff;
+  const int a = min(p, q), b = max(p, q);
+  int mc;
+  const float pr = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.ocls[a], X.ocls[b],
+                               1, 1, oml, &mc);
+  const u64 key = mn_key(a, b);
+  X.rkey[rid] = key;
+  X.roml[rid] = oml;
+  X.leaf[rid] = mn_x_word(pr);
+  unsigned s = mn_hash(key) & X.hmask;
+  for (;;) {
+    const u64 old = atomicCAS(&X.hkey[s], MN_X_HEMPTY, key);
+    if (old == MN_X_HEMPTY) break;
+    s = (s + 1) & X.hmask;
+  }
+  X.hval[s] = rid;
+  X.rslot[rid] = s;
+  X.arena[(size_t)p * X.cap0 + k] = rid;
+  X.arena[(size_t)q * X.cap0 + P.O + k] = rid;
+}
+
+// block maxima of the queue words
+__global__ __launch_bounds__(64) void mn_x_build_l1(XState X) {
+  const unsigned blk = blockIdx.x;
+  const unsigned base = blk << X.Blog;
+  const int B = 1 << X.Blog;
+  u64 m = 0;
+  for (int i = threadIdx.x; i < B; i += 64)
+    if (base + i < X.NL) {
+      const u64 e = mn_x_pack(X.leaf[base + i], base + i);
+      m = e > m ? e : m;
+    }
+  m = mn_x_wave_max(m);
+  if (threadIdx.x == 0) X.l1g[blk] = m;
+}
+
+// ---- the loop ----------------------------------------------------------------------------------------
+#define MN_X_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define MN_X_MEM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+
+// maximum (word, record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads
+__device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned base, int B, unsigned skip,
+                                               int lane) {
+  u64 m = 0;
+  for (int i0 = 0; i0 < B; i0 += 1024) {
+    uint4 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * 256 + lane * 4;
+      w[j] = (i < B) ? *reinterpret_cast<const uint4*>(leaf + base + i) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned id = base + (unsigned)(i0 + j * 256 + lane * 4);
+      u64 e;
+      e = (id != skip) ? mn_x_pack(w[j].x, id) : 0ull;         m = e > m ? e : m;
+      e = (id + 1 != skip) ? mn_x_pack(w[j].y, id + 1) : 0ull; m = e > m ? e : m;
+      e = (id + 2 != skip) ? mn_x_pack(w[j].z, id + 2) : 0ull; m = e > m ? e : m;
+      e = (id + 3 != skip) ? mn_x_pack(w[j].w, id + 3) : 0ull; m = e > m ? e : m;
+    }
+  }
+  return mn_x_wave_max(m);
+}
+
+__device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int lane) {
+  const u64 v = mn_x_wave_max(l1[g * 64 + lane]);
+  if (lane == 0) l2[g] = v;
+}
+
+__global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long budget) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x_smem[];
+  u64* l1 = reinterpret_cast<u64*>(x_smem);                        // [NBpad]
+  u64* l2 = l1 + X.NBpad;                                          // [NG]
+  float* sh_lpa = reinterpret_cast<float*>(l2 + X.NG);             // [128] survivor's new class vector
+  unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups whose maxima changed
+  const int lane = threadIdx.x;
+  const int C = P.C;
+  const int B = 1 << X.Blog;
+
+  for (int i = lane; i < X.NBpad; i += 64) l1[i] = (i < X.NB) ? X.l1g[i] : 0ull;
+  if (lane < 8) sh_gmask[lane] = 0u;
+  MN_X_LDS_SYNC();
+  for (int g = 0; g < X.NG; g++) mn_x_group_refresh(l1, l2, g, lane);
+  MN_X_LDS_SYNC();
+
+  long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0;
+  unsigned long long bump = X.ctl->bump;
+  int status = MN_X_RUNNING;
+
+  for (;;) {
+    // ---- pop: the largest (word, lowest record id) ----
+    u64 top = 0;
+    for (int g = lane; g < X.NG; g += 64) { const u64 v = l2[g]; top = v > top ? v : top; }
+    top = mn_x_wave_max(top);
+    const unsigned gword = (unsigned)(top >> 32);
+    if (gword == 0u) { status = MN_X_DONE; break; }
+    if (top == MN_X_DIRTY) { status = MN_ERR_INTERNAL; break; }
+    if (steps >= budget) { status = MN_X_BUDGET; break; }
+    const unsigned rid = mn_x_rid(top);
+    const unsigned blk = rid >> X.Blog;
+    // the record, and beside it the popped block without it (its maximum changes either way)
+    const u64 key = X.rkey[rid];
+    const float S = X.roml[rid];
+    const unsigned slot_r = X.rslot[rid];
+    const u64 bm = mn_x_scan_block(X.leaf, blk << X.Blog, B, rid, lane);
+    if (key == MN_EMPTY) { status = MN_ERR_INTERNAL; break; }
+    const int x = mn_key_u(key), y = mn_key_v(key);
+    // ---- re-score (segment.cc:560): both objects' state in one round trip ----
+    const int nx = X.osize[x], ny = X.osize[y];
+    const int cx = X.ocls[x], cy = X.ocls[y];
+    const unsigned ptrx = X.aptr[x], ptry = X.aptr[y];
+    const int lenx = X.alen[x], leny = X.alen[y], capx = X.acap[x], capy = X.acap[y];
+    float ax0 = 0.0f, ay0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f;
+    if (lane < C) { ax0 = X.lp[(size_t)x * C + lane]; ay0 = X.lp[(size_t)y * C + lane]; }
+    if (lane + 64 < C) { ax1 = X.lp[(size_t)x * C + lane + 64]; ay1 = X.lp[(size_t)y * C + lane + 64]; }
+    float cdl = 0.0f;
+    int mc = cx;
+    if (cx != cy) {
+      // first maximum of the joint vector: highest value, lowest class among equals
+      float j = ax0 + ay0;
+      int jc = lane;
+      bool ok = lane < C;
+      if (lane + 64 < C) {
+        const float j1 = ax1 + ay1;
+        if (j1 > j) { j = j1; jc = lane + 64; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float oj = __shfl_xor(j, off);
+        const int oc = __shfl_xor(jc, off);
+        const bool ook = __shfl_xor((int)ok, off) != 0;
+        const bool take = ook && (!ok || oj > j || (oj == j && oc < jc));
+        if (take) { j = oj; jc = oc; ok = true; }
+      }
+      const float lx = cx < 64 ? __shfl(ax0, cx) : __shfl(ax1, cx - 64);
+      const float ly = cy < 64 ? __shfl(ay0, cy) : __shfl(ay1, cy - 64);
+      cdl = (j - lx) - ly;
+      mc = jc;
+    }
+    const float den = (float)((unsigned long long)nx + (unsigned long long)ny);
+    const float f = (S * P.omf + cdl) / den + P.bias;
+    const unsigned fw = mn_x_word(f);
+    steps++;
+    if (fw != gword) {
+      // ---- not what the queue promised: store the fresh value (segment.cc:563-565) ----
+      if (lane == 0) {
+        X.leaf[rid] = fw;
+        const u64 e = mn_x_pack(fw, rid);
+        l1[blk] = e > bm ? e : bm;
+      }
+      MN_X_LDS_SYNC();
+      mn_x_group_refresh(l1, l2, (int)(blk >> 6), lane);
+      MN_X_LDS_SYNC();
+      continue;
+    }
+
+    // ---- merge (segment.cc:602-727): the larger object survives, a tie keeps the lower id ----
+    const bool swap = nx < ny;
+    const int a = swap ? y : x, b = swap ? x : y;
+    unsigned pa = swap ? ptry : ptrx;
+    const unsigned pb = swap ? ptrx : ptry;
+    int la = swap ? leny : lenx;
+    const int lb = swap ? lenx : leny;
+    int capa = swap ? capy : capx;
+    // room for the records the survivor may adopt; checked before anything is changed, so that a
+    // full arena leaves a consistent state behind
+    bool moved = false;
+    unsigned newp = 0;
+    int newcap = 0;
+    if (la + lb > capa) {
+      newcap = ((2 * (la + lb) + 63) / 64) * 64;
+      if (bump + (unsigned long long)newcap > X.arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
+      newp = (unsigned)bump;
+      bump += (unsigned long long)newcap;
+      moved = true;
+    }
+    merges++;
+    // object state of the survivor (:635-642); the absorbed object only keeps its parent link
+    if (lane < C) { const float s0 = ax0 + ay0; X.lp[(size_t)a * C + lane] = s0; sh_lpa[lane] = s0; }
+    if (lane + 64 < C) { const float s1 = ax1 + ay1; X.lp[(size_t)a * C + lane + 64] = s1; sh_lpa[lane + 64] = s1; }
+    const int na = nx + ny;
+    if (lane == 0) {
+      X.osize[a] = na;
+      X.ocls[a] = (unsigned char)mc;
+      X.parent[b] = a;
+      X.rkey[rid] = MN_EMPTY;                  // the merged record leaves every list (:645-647)
+      X.leaf[rid] = 0u;
+      X.hkey[slot_r] = MN_X_HTOMB;
+      l1[blk] = bm;
+      sh_gmask[blk >> 11] |= 1u << ((blk >> 6) & 31u);
+    }
+    MN_X_LDS_SYNC();
+    if (moved) {
+      // the survivor's live entries move to a larger array
+      int cnt = 0;
+      for (int j0 = 0; j0 < la; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned e = (j < la) ? X.arena[(size_t)pa + j] : MN_X_INVALID;
+        bool live = e != MN_X_INVALID && e != rid;
+        if (live) live = X.rkey[e] != MN_EMPTY;
+        const u64 mk = __ballot(live);
+        if (live) X.arena[(size_t)newp + cnt + __popcll(mk & ((1ull << lane) - 1ull))] = e;
+        cnt += __popcll(mk);
+      }
+      pa = newp; la = cnt; capa = newcap;
+      reallocs++;
+      if (lane == 0) { X.aptr[a] = pa; X.acap[a] = capa; }
+    }
+    // ---- the absorbed object's records (:650-707), 64 per pass ----
+    for (int j0 = 0; j0 < lb; j0 += 64) {
+      const int j = j0 + lane;
+      const unsigned e = (j < lb) ? X.arena[(size_t)pb + j] : MN_X_INVALID;
+      bool live = e != MN_X_INVALID && e != rid;
+      u64 kt = MN_EMPTY;
+      float St = 0.0f;
+      unsigned slot_t = 0;
+      if (live) { kt = X.rkey[e]; St = X.roml[e]; slot_t = X.rslot[e]; }
+      live = live && kt != MN_EMPTY;
+      const int c3 = live ? ((mn_key_u(kt) == b) ? mn_key_v(kt) : mn_key_u(kt)) : 0;
+      // the third object's state and the table look-up of (survivor, third) in one round trip
+      int n3 = 0, cc3 = 0;
+      u64 key2 = 0;
+      int found = -1, freeslot = -1;
+      u64 freeval = 0;
+      bool hfull = false;
+      if (live) {
+        n3 = X.osize[c3];
+        cc3 = X.ocls[c3];
+        key2 = mn_key(a, c3);
+        unsigned s = mn_hash(key2) & X.hmask;
+        for (int guard = 0;; guard++) {
+          const u64 hk = X.hkey[s];
+          if (hk == key2) { found = (int)s; break; }
+          if (hk == MN_X_HEMPTY) { if (freeslot < 0) { freeslot = (int)s; freeval = hk; } break; }
+          if (hk == MN_X_HTOMB && freeslot < 0) { freeslot = (int)s; freeval = hk; }
+          s = (s + 1) & X.hmask;
+          if (guard > (1 << 22)) { hfull = true; break; }
+        }
+      }
+      if (__ballot(hfull)) { status = MN_X_HASH_FULL; break; }   // (uniform: nothing of this pass was written yet)
+      unsigned tr = MN_X_INVALID;   // the record this lane re-scores
+      float Sn = St;
+      const bool fold = live && found >= 0;
+      const bool adopt = live && found < 0;
+      if (fold) {
+        // the survivor already has a record with the third object: add (:690-692), retire this one (:694)
+        tr = X.hval[found];
+        Sn = X.roml[tr] + St;
+        X.roml[tr] = Sn;
+        X.rkey[e] = MN_EMPTY;
+        X.leaf[e] = 0u;
+        X.hkey[slot_t] = MN_X_HTOMB;
+      }
+      const u64 am = __ballot(adopt);
+      if (adopt) {
+        // re-key (:659-664, 677), adopt into the survivor's list (:700-702)
+        tr = e;
+        X.rkey[e] = key2;
+        X.hkey[slot_t] = MN_X_HTOMB;
+        unsigned s = (unsigned)freeslot;
+        u64 expect = freeval;
+        for (;;) {
+          const u64 old = atomicCAS(&X.hkey[s], expect, key2);
+          if (old == expect) break;
+          // taken by another lane of this pass: next free slot of the chain
+          for (int guard = 0; guard < (1 << 24); guard++) {
+            s = (s + 1) & X.hmask;
+            const u64 hk = X.hkey[s];
+            if (hk == MN_X_HEMPTY || hk == MN_X_HTOMB) { expect = hk; break; }
+          }
+        }
+        X.hval[s] = e;
+        X.rslot[e] = s;
+        X.arena[(size_t)pa + la + __popcll(am & ((1ull << lane) - 1ull))] = e;
+      }
+      la += __popcll(am);
+      adopted += __popcll(am);
+      folded += __popcll(__ballot(fold));
+      // re-score what was touched (:695-698, 703-706) with the survivor's new state
+      unsigned w = 0u;
+      if (live) {
+        const float pr = mn_x_score_fold(P, sh_lpa, X.lp + (size_t)c3 * C, mc, cc3, na, n3, Sn, a < c3);
+        w = mn_x_word(pr);
+        X.leaf[tr] = w;
+      }
+      // ---- queue: block maxima of the retired and the re-scored records; a block whose maximum was
+      //      lowered or removed is marked and re-read at the end of the step ----
+      if (fold) {
+        const unsigned be = e >> X.Blog;
+        const u64 cur = l1[be];
+        if (cur != 0ull && mn_x_rid(cur) == e) atomicMax(&l1[be], MN_X_DIRTY);
+        atomicOr(&sh_gmask[be >> 11], 1u << ((be >> 6) & 31u));
+      }
+      if (live) {
+        const unsigned bt = tr >> X.Blog;
+        const u64 cur = l1[bt];
+        const u64 ne = mn_x_pack(w, tr);
+        if (cur != 0ull && cur != MN_X_DIRTY && mn_x_rid(cur) == tr && ne < cur) atomicMax(&l1[bt], MN_X_DIRTY);
+        else if (ne) atomicMax(&l1[bt], ne);
+        atomicOr(&sh_gmask[bt >> 11], 1u << ((bt >> 6) & 31u));
+      }
+      MN_X_MEM_SYNC();   // this pass's stores and atomics before the next pass's loads
+    }
+    if (status != MN_X_RUNNING) break;
+    if (lane == 0) X.alen[a] = la;
+    MN_X_MEM_SYNC();   // this step's stores and atomics before the next step's loads
+    // ---- re-read the blocks whose maximum was lowered or removed, then the groups ----
+    for (int wd = 0; wd < 8; wd++) {
+      unsigned m = sh_gmask[wd];
+      while (m) {
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const int g = wd * 32 + bit;
+        u64 dm = __ballot(l1[g * 64 + lane] == MN_X_DIRTY);
+        while (dm) {
+          const unsigned bb = (unsigned)(g * 64 + __ffsll((long long)dm) - 1);
+          dm &= dm - 1ull;
+          const u64 v = mn_x_scan_block(X.leaf, bb << X.Blog, B, MN_X_INVALID, lane);
+          if (lane == 0) l1[bb] = v;
+          rescans++;
+        }
+        MN_X_LDS_SYNC();
+        mn_x_group_refresh(l1, l2, g, lane);
+      }
+    }
+    MN_X_LDS_SYNC();
+    if (lane < 8) sh_gmask[lane] = 0u;
+    MN_X_LDS_SYNC();
+  }
+
+  if (lane == 0) {
+    XCtl* c = X.ctl;
+    c->status = status;
+    c->steps += steps; c->merges += merges; c->rescans += rescans; c->reallocs += reallocs;
+    c->folded += folded; c->adopted += adopted;
+    c->bump = bump;
+  }
+}
+
+// ---- hand-over to the output stage -------------------------------------------------------------------
+// The output kernels read the class sums of live objects from the plane-major table (mn_obj_lp):
+// copy the survivors' vectors there.
+__global__ __launch_bounds__(256) void mn_x_export_objects(ImgParams P, XState X, float* __restrict__ lpsum,
+                                                           unsigned char* __restrict__ lpvalid) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  const bool root = X.parent[p] == p;
+  lpvalid[p] = root ? 1 : 0;
+  if (!root) return;
+  for (int c = 0; c < P.C; c++) lpsum[(size_t)c * P.N + p] = X.lp[(size_t)p * P.C + c];
+}
+
+// Quotient condition of the certificate on the engine's own records: no record between two final
+// objects may still be mergeable (cf. mn_verify_records).
+__global__ __launch_bounds__(256) void mn_x_verify_records(ImgParams P, XState X, int* __restrict__ violations) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= X.NL) return;
+  const u64 key = X.rkey[i];
+  if (key == MN_EMPTY) return;
+  const int a = mn_key_u(key), b = mn_key_v(key);
+  int mc;
+  const float f = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.ocls[a], X.ocls[b],
+                              X.osize[a], X.osize[b], X.roml[i], &mc);
+  const float margin = 1e-6f + 1e-5f * fabsf(P.bias);
+  if (!(f < -margin)) atomicAdd(violations + 4, 1);
+}
