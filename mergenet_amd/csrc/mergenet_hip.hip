@@ -166,7 +166,7 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
 // ---- exact engine: workspace ------------------------------------------------------------------------
 static void x_free(mn_context* c) {
   XState& X = c->xw.X;
-  void* dev[] = {X.rkey, X.roml, X.leaf, X.rslot, X.hkey, X.hval, X.lp, X.aptr, X.alen, X.acap, X.arena, X.l1g, X.ctl};
+  void* dev[] = {X.rkey, X.roml, X.leaf, X.rslot, X.hs, X.lp, X.aptr, X.alen, X.acap, X.arena, X.l1g, X.ctl};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
@@ -206,8 +206,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
     MN_HIP(x_alloc(c, &X.roml, NL));
     MN_HIP(x_alloc(c, &X.leaf, leaf_cap));
     MN_HIP(x_alloc(c, &X.rslot, NL));
-    MN_HIP(x_alloc(c, &X.hkey, hcap));
-    MN_HIP(x_alloc(c, &X.hval, hcap));
+    MN_HIP(x_alloc(c, &X.hs, hcap));
     MN_HIP(x_alloc(c, &X.lp, (size_t)N * C));
     MN_HIP(x_alloc(c, &X.aptr, (size_t)N));
     MN_HIP(x_alloc(c, &X.alen, (size_t)N));
@@ -861,7 +860,7 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   mn_context::XWork& w = c->xw;
   XState& X = w.X;
   const size_t N = (size_t)P.N;
-  MN_HIP(hipMemsetAsync(X.hkey, 0xFF, ((size_t)X.hmask + 1) * sizeof(u64), st));
+  MN_HIP(hipMemsetAsync(X.hs, 0xFF, ((size_t)X.hmask + 1) * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.arena, 0xFF, N * (size_t)X.cap0 * sizeof(unsigned), st));
   MN_HIP(hipMemsetAsync(X.leaf, 0, ((size_t)X.NB << X.Blog) * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
@@ -871,7 +870,7 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   MN_HIP(hipEventRecord(c->ev[1], st));
   hipLaunchKernelGGL(mn_x_init_records, dim3(grid_for((size_t)X.NL, 256)), dim3(256), 0, st, P, X);
   MN_HIP(hipEventRecord(c->ev[2], st));
-  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 64;
+  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 256 * 4 + 64;
   if (!w.lds_ready) {
     MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));

@@ -47,15 +47,22 @@ struct XCtl {
   unsigned long long bump;    // next free arena entry
 };
 
+// one slot of the pair table: key, the record that carries it, and a copy of its log-odds sum (a fold
+// then needs no further round trip for the sum; roml[] keeps the copy the pop reads)
+struct __attribute__((aligned(16))) XSlot {
+  u64 key;
+  unsigned rid;
+  float S;
+};
+
 struct XState {
   // records, indexed by record id (pixel * O + k)
   u64* rkey;                  // (lower object id << 32) | higher; MN_EMPTY = dead / never existed
   float* roml;                // AdjacencyRecord::obj_merge_logprob (float32, segment.cc:36, 690)
   unsigned* leaf;             // queue word of the stored priority: 0 = not queued
   unsigned* rslot;            // slot of the record's key in the pair table
-  // pair table
-  u64* hkey;
-  unsigned* hval;
+  // pair table: 16-byte slots
+  XSlot* hs;
   unsigned hmask;
   // objects
   float* lp;                  // [N][C] Object::class_logprobs (float32 sums, segment.cc:640)
@@ -130,6 +137,38 @@ __device__ __forceinline__ u64 mn_x_pack(unsigned w, unsigned rid) {
   return w ? (((u64)w << 32) | (u64)(0xFFFFFFFFu - rid)) : 0ull;
 }
 __device__ __forceinline__ unsigned mn_x_rid(u64 e) { return 0xFFFFFFFFu - (unsigned)e; }
+
+// Wave-wide reductions on the VALU (DPP row moves + four readlanes; a ds_bpermute-based __shfl_xor
+// costs an LDS round trip per step, and this loop does several reductions per step).  All lanes get
+// the result.
+__device__ __forceinline__ unsigned mn_x_wmax_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ float mn_x_wmax_f32(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// maximum of (word << 32 | ~record id) entries: the word first, then the low half among its holders
+__device__ __forceinline__ u64 mn_x_wmax_pair(u64 v) {
+  const unsigned hi = (unsigned)(v >> 32);
+  const unsigned mh = mn_x_wmax_u32(hi);
+  const unsigned lo = (hi == mh) ? (unsigned)v : 0u;
+  const unsigned ml = mn_x_wmax_u32(lo);
+  return ((u64)mh << 32) | (u64)ml;
+}
 
 __device__ __forceinline__ u64 mn_x_shfl_xor(u64 v, int off) {
   const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off);
@@ -258,11 +297,12 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
   X.leaf[rid] = mn_x_word(pr);
   unsigned s = mn_hash(key) & X.hmask;
   for (;;) {
-    const u64 old = atomicCAS(&X.hkey[s], MN_X_HEMPTY, key);
+    const u64 old = atomicCAS(&X.hs[s].key, MN_X_HEMPTY, key);
     if (old == MN_X_HEMPTY) break;
     s = (s + 1) & X.hmask;
   }
-  X.hval[s] = rid;
+  X.hs[s].rid = rid;
+  X.hs[s].S = oml;
   X.rslot[rid] = s;
   X.arena[(size_t)p * X.cap0 + k] = rid;
   X.arena[(size_t)q * X.cap0 + P.O + k] = rid;
@@ -284,13 +324,23 @@ __global__ __launch_bounds__(64) void mn_x_build_l1(XState X) {
 }
 
 // ---- the loop ----------------------------------------------------------------------------------------
+// One wavefront; cross-lane traffic through LDS is ordered by waiting for the LDS counter (a memory
+// clobber keeps the compiler from moving accesses across it).  Global memory: the engine's loads, stores
+// and its dependent loads of the same addresses are issued by ONE wave in program order, which the
+// memory pipeline preserves per address; -DMN_X_PARANOID drains the vector-memory counter after every
+// pass and step (results compared equal with and without on every reference vector).
 #define MN_X_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef MN_X_PARANOID
 #define MN_X_MEM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define MN_X_MEM_SYNC() asm volatile("" ::: "memory")
+#endif
 
-// maximum (word, record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads
+// maximum (word, lowest record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads.
+// Words first (one v_max per leaf), then the lowest record id among the holders of the maximum.
 __device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned base, int B, unsigned skip,
                                                int lane) {
-  u64 m = 0;
+  unsigned best = 0u, bestid = MN_X_INVALID;
   for (int i0 = 0; i0 < B; i0 += 1024) {
     uint4 w[4];
 #pragma unroll
@@ -301,18 +351,22 @@ __device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned ba
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const unsigned id = base + (unsigned)(i0 + j * 256 + lane * 4);
-      u64 e;
-      e = (id != skip) ? mn_x_pack(w[j].x, id) : 0ull;         m = e > m ? e : m;
-      e = (id + 1 != skip) ? mn_x_pack(w[j].y, id + 1) : 0ull; m = e > m ? e : m;
-      e = (id + 2 != skip) ? mn_x_pack(w[j].z, id + 2) : 0ull; m = e > m ? e : m;
-      e = (id + 3 != skip) ? mn_x_pack(w[j].w, id + 3) : 0ull; m = e > m ? e : m;
+      if ((skip & ~3u) == id) {
+        const unsigned q = skip & 3u;
+        if (q == 0) w[j].x = 0u; else if (q == 1) w[j].y = 0u; else if (q == 2) w[j].z = 0u; else w[j].w = 0u;
+      }
+      // (descending ids, so that among equal words the lowest id is the one kept)
+      if (w[j].w > best || (w[j].w == best && id + 3 < bestid)) { best = w[j].w; bestid = id + 3; }
+      if (w[j].z > best || (w[j].z == best && id + 2 < bestid)) { best = w[j].z; bestid = id + 2; }
+      if (w[j].y > best || (w[j].y == best && id + 1 < bestid)) { best = w[j].y; bestid = id + 1; }
+      if (w[j].x > best || (w[j].x == best && id < bestid)) { best = w[j].x; bestid = id; }
     }
   }
-  return mn_x_wave_max(m);
+  return mn_x_wmax_pair(mn_x_pack(best, bestid));
 }
 
 __device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int lane) {
-  const u64 v = mn_x_wave_max(l1[g * 64 + lane]);
+  const u64 v = mn_x_wmax_pair(l1[g * 64 + lane]);
   if (lane == 0) l2[g] = v;
 }
 
@@ -322,6 +376,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
   u64* l2 = l1 + X.NBpad;                                          // [NG]
   float* sh_lpa = reinterpret_cast<float*>(l2 + X.NG);             // [128] survivor's new class vector
   unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups whose maxima changed
+  unsigned* sh_ctab = sh_gmask + 8;                                // [256] same-slot check of a pass's inserts
   const int lane = threadIdx.x;
   const int C = P.C;
   const int B = 1 << X.Blog;
@@ -340,7 +395,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     // ---- pop: the largest (word, lowest record id) ----
     u64 top = 0;
     for (int g = lane; g < X.NG; g += 64) { const u64 v = l2[g]; top = v > top ? v : top; }
-    top = mn_x_wave_max(top);
+    top = mn_x_wmax_pair(top);
     const unsigned gword = (unsigned)(top >> 32);
     if (gword == 0u) { status = MN_X_DONE; break; }
     if (top == MN_X_DIRTY) { status = MN_ERR_INTERNAL; break; }
@@ -366,25 +421,23 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     int mc = cx;
     if (cx != cy) {
       // first maximum of the joint vector: highest value, lowest class among equals
-      float j = ax0 + ay0;
-      int jc = lane;
-      bool ok = lane < C;
+      const float ninf = -__builtin_huge_valf();
+      float j = (lane < C) ? (ax0 + ay0) : ninf;
+      bool second = false;
       if (lane + 64 < C) {
         const float j1 = ax1 + ay1;
-        if (j1 > j) { j = j1; jc = lane + 64; }
+        if (j1 > j) { j = j1; second = true; }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float oj = __shfl_xor(j, off);
-        const int oc = __shfl_xor(jc, off);
-        const bool ook = __shfl_xor((int)ok, off) != 0;
-        const bool take = ook && (!ok || oj > j || (oj == j && oc < jc));
-        if (take) { j = oj; jc = oc; ok = true; }
-      }
-      const float lx = cx < 64 ? __shfl(ax0, cx) : __shfl(ax1, cx - 64);
-      const float ly = cy < 64 ? __shfl(ay0, cy) : __shfl(ay1, cy - 64);
-      cdl = (j - lx) - ly;
-      mc = jc;
+      const float jm = mn_x_wmax_f32(j);
+      const u64 m1 = __ballot(j == jm && !second && lane < C);
+      const u64 m2 = __ballot(j == jm && second);
+      mc = m1 ? (__ffsll((long long)m1) - 1) : (64 + __ffsll((long long)m2) - 1);
+      const int cxs = __builtin_amdgcn_readfirstlane(cx), cys = __builtin_amdgcn_readfirstlane(cy);
+      const float lx = cxs < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax0), cxs))
+                                : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax1), cxs - 64));
+      const float ly = cys < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay0), cys))
+                                : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay1), cys - 64));
+      cdl = (jm - lx) - ly;
     }
     const float den = (float)((unsigned long long)nx + (unsigned long long)ny);
     const float f = (S * P.omf + cdl) / den + P.bias;
@@ -417,7 +470,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     unsigned newp = 0;
     int newcap = 0;
     if (la + lb > capa) {
-      newcap = ((2 * (la + lb) + 63) / 64) * 64;
+      newcap = ((3 * (la + lb) + 63) / 64) * 64;
       if (bump + (unsigned long long)newcap > X.arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
       newp = (unsigned)bump;
       bump += (unsigned long long)newcap;
@@ -434,7 +487,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       X.parent[b] = a;
       X.rkey[rid] = MN_EMPTY;                  // the merged record leaves every list (:645-647)
       X.leaf[rid] = 0u;
-      X.hkey[slot_r] = MN_X_HTOMB;
+      X.hs[slot_r].key = MN_X_HTOMB;
       l1[blk] = bm;
       sh_gmask[blk >> 11] |= 1u << ((blk >> 6) & 31u);
     }
@@ -455,6 +508,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       reallocs++;
       if (lane == 0) { X.aptr[a] = pa; X.acap[a] = capa; }
     }
+    const float la_c = sh_lpa[mc];
     // ---- the absorbed object's records (:650-707), 64 per pass ----
     for (int j0 = 0; j0 < lb; j0 += 64) {
       const int j = j0 + lane;
@@ -466,61 +520,86 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       if (live) { kt = X.rkey[e]; St = X.roml[e]; slot_t = X.rslot[e]; }
       live = live && kt != MN_EMPTY;
       const int c3 = live ? ((mn_key_u(kt) == b) ? mn_key_v(kt) : mn_key_u(kt)) : 0;
-      // the third object's state and the table look-up of (survivor, third) in one round trip
+      // ONE round trip: the third object's state (its first sixteen class terms included) and the
+      // first slot of the table look-up of (survivor, third)
       int n3 = 0, cc3 = 0;
       u64 key2 = 0;
       int found = -1, freeslot = -1;
-      u64 freeval = 0;
+      float Su = 0.0f;
+      unsigned u_rid = MN_X_INVALID;
+      float v3[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v3[q] = 0.0f;
       bool hfull = false;
       if (live) {
+        const float* l3 = X.lp + (size_t)c3 * C;
         n3 = X.osize[c3];
         cc3 = X.ocls[c3];
+#pragma unroll
+        for (int q = 0; q < 16; q++) if (q < C) v3[q] = l3[q];
         key2 = mn_key(a, c3);
         unsigned s = mn_hash(key2) & X.hmask;
         for (int guard = 0;; guard++) {
-          const u64 hk = X.hkey[s];
-          if (hk == key2) { found = (int)s; break; }
-          if (hk == MN_X_HEMPTY) { if (freeslot < 0) { freeslot = (int)s; freeval = hk; } break; }
-          if (hk == MN_X_HTOMB && freeslot < 0) { freeslot = (int)s; freeval = hk; }
+          const uint4 raw = *reinterpret_cast<const uint4*>(&X.hs[s]);
+          const u64 hk = ((u64)raw.y << 32) | (u64)raw.x;
+          if (hk == key2) { found = (int)s; u_rid = raw.z; Su = __uint_as_float(raw.w); break; }
+          if (hk == MN_X_HEMPTY) { if (freeslot < 0) freeslot = (int)s; break; }
+          if (hk == MN_X_HTOMB && freeslot < 0) freeslot = (int)s;
           s = (s + 1) & X.hmask;
           if (guard > (1 << 22)) { hfull = true; break; }
         }
       }
-      if (__ballot(hfull)) { status = MN_X_HASH_FULL; break; }   // (uniform: nothing of this pass was written yet)
+      if (__ballot(hfull)) { status = MN_X_HASH_FULL; break; }
       unsigned tr = MN_X_INVALID;   // the record this lane re-scores
       float Sn = St;
       const bool fold = live && found >= 0;
       const bool adopt = live && found < 0;
       if (fold) {
         // the survivor already has a record with the third object: add (:690-692), retire this one (:694)
-        tr = X.hval[found];
-        Sn = X.roml[tr] + St;
+        tr = u_rid;
+        Sn = Su + St;
         X.roml[tr] = Sn;
+        X.hs[found].S = Sn;
         X.rkey[e] = MN_EMPTY;
         X.leaf[e] = 0u;
-        X.hkey[slot_t] = MN_X_HTOMB;
+        X.hs[slot_t].key = MN_X_HTOMB;
       }
       const u64 am = __ballot(adopt);
-      if (adopt) {
-        // re-key (:659-664, 677), adopt into the survivor's list (:700-702)
-        tr = e;
-        X.rkey[e] = key2;
-        X.hkey[slot_t] = MN_X_HTOMB;
-        unsigned s = (unsigned)freeslot;
-        u64 expect = freeval;
-        for (;;) {
-          const u64 old = atomicCAS(&X.hkey[s], expect, key2);
-          if (old == expect) break;
-          // taken by another lane of this pass: next free slot of the chain
-          for (int guard = 0; guard < (1 << 24); guard++) {
-            s = (s + 1) & X.hmask;
-            const u64 hk = X.hkey[s];
-            if (hk == MN_X_HEMPTY || hk == MN_X_HTOMB) { expect = hk; break; }
-          }
+      if (am) {
+        // re-key (:659-664, 677), adopt into the survivor's list (:700-702).  Two lanes of a pass may
+        // have found the same free slot: the first writer of a 256-entry LDS tag keeps it, the others
+        // look again one after the other (rare)
+        if (adopt) sh_ctab[(unsigned)freeslot & 255u] = (unsigned)lane;
+        MN_X_LDS_SYNC();
+        const bool clash = adopt && sh_ctab[(unsigned)freeslot & 255u] != (unsigned)lane;
+        if (adopt) {
+          tr = e;
+          X.rkey[e] = key2;
+          X.hs[slot_t].key = MN_X_HTOMB;
+          X.arena[(size_t)pa + la + __popcll(am & ((1ull << lane) - 1ull))] = e;
         }
-        X.hval[s] = e;
-        X.rslot[e] = s;
-        X.arena[(size_t)pa + la + __popcll(am & ((1ull << lane) - 1ull))] = e;
+        if (adopt && !clash) {
+          XSlot ns; ns.key = key2; ns.rid = e; ns.S = St;
+          *reinterpret_cast<uint4*>(&X.hs[freeslot]) = *reinterpret_cast<const uint4*>(&ns);
+          X.rslot[e] = (unsigned)freeslot;
+        }
+        u64 cm = __ballot(clash);
+        while (cm) {
+          const int l = __ffsll((long long)cm) - 1;
+          cm &= cm - 1ull;
+          if (lane == l) {
+            unsigned s = mn_hash(key2) & X.hmask;
+            for (int guard = 0; guard < (1 << 22); guard++) {
+              const u64 hk = X.hs[s].key;
+              if (hk == MN_X_HEMPTY || hk == MN_X_HTOMB) break;
+              s = (s + 1) & X.hmask;
+            }
+            XSlot ns; ns.key = key2; ns.rid = e; ns.S = St;
+            *reinterpret_cast<uint4*>(&X.hs[s]) = *reinterpret_cast<const uint4*>(&ns);
+            X.rslot[e] = s;
+          }
+          MN_X_MEM_SYNC();
+        }
       }
       la += __popcll(am);
       adopted += __popcll(am);
@@ -528,8 +607,26 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       // re-score what was touched (:695-698, 703-706) with the survivor's new state
       unsigned w = 0u;
       if (live) {
-        const float pr = mn_x_score_fold(P, sh_lpa, X.lp + (size_t)c3 * C, mc, cc3, na, n3, Sn, a < c3);
-        w = mn_x_word(pr);
+        float cdl3 = 0.0f;
+        if (mc != cc3) {
+          const float* l3 = X.lp + (size_t)c3 * C;
+          const float l3_c = l3[cc3];
+          float bestv = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 16; q++)
+            if (q < C) { const float v = sh_lpa[q] + v3[q]; if (q == 0 || v > bestv) bestv = v; }
+          for (int c0 = 16; c0 < C; c0 += 16) {
+            float vb[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) vb[q] = (c0 + q < C) ? l3[c0 + q] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+              if (c0 + q < C) { const float v = sh_lpa[c0 + q] + vb[q]; if (v > bestv) bestv = v; }
+          }
+          cdl3 = (a < c3) ? ((bestv - la_c) - l3_c) : ((bestv - l3_c) - la_c);
+        }
+        const float den3 = (float)((unsigned long long)na + (unsigned long long)n3);
+        w = mn_x_word((Sn * P.omf + cdl3) / den3 + P.bias);
         X.leaf[tr] = w;
       }
       // ---- queue: block maxima of the retired and the re-scored records; a block whose maximum was
@@ -548,11 +645,12 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         else if (ne) atomicMax(&l1[bt], ne);
         atomicOr(&sh_gmask[bt >> 11], 1u << ((bt >> 6) & 31u));
       }
-      MN_X_MEM_SYNC();   // this pass's stores and atomics before the next pass's loads
+      MN_X_LDS_SYNC();
+      MN_X_MEM_SYNC();   // (paranoid build: this pass's stores before the next pass's loads)
     }
     if (status != MN_X_RUNNING) break;
     if (lane == 0) X.alen[a] = la;
-    MN_X_MEM_SYNC();   // this step's stores and atomics before the next step's loads
+    MN_X_MEM_SYNC();
     // ---- re-read the blocks whose maximum was lowered or removed, then the groups ----
     for (int wd = 0; wd < 8; wd++) {
       unsigned m = sh_gmask[wd];
