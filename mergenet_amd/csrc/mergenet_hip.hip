@@ -166,7 +166,7 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
 // ---- exact engine: workspace ------------------------------------------------------------------------
 static void x_free(mn_context* c) {
   XState& X = c->xw.X;
-  void* dev[] = {X.rkey, X.roml, X.leaf, X.rslot, X.hs, X.lp, X.aptr, X.alen, X.acap, X.arena, X.l1g, X.ctl};
+  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
@@ -183,8 +183,8 @@ static hipError_t x_alloc(mn_context* c, T** p, size_t n) {
 }
 
 // Sizes the workspace for an image of N pixels, O offsets, C classes.  Per pixel (C = 9, O = 10):
-// records 20 B x O, pair table ~38 B x O, class vectors 4 B x C, adjacency arena 4 B x 384:
-// ~2.2 KB, 4.6 GB for 1024 x 2048 (of 288 GB).
+// records 20 B x O, pair table 64-128 B x O, class vectors 4 B x C, objects 20 B, adjacency arena
+// 4 B x 384: ~3 KB, 6 GB for 1024 x 2048 (of 288 GB).
 static int x_ensure(mn_context* c, int N, int O, int C) {
   mn_context::XWork& w = c->xw;
   const size_t NL = (size_t)N * O;
@@ -192,34 +192,35 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   size_t B = 256;
   while ((NL + B - 1) / B > MN_X_MAXBLOCKS) B <<= 1;
   const size_t NB = (NL + B - 1) / B;
-  const size_t leaf_cap = NB * B;
-  const size_t hcap = next_pow2(2 * NL + 1024);
+  const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
+  const size_t nbuckets = next_pow2(NL + 256);       // 4 slots each: load <= 0.25
+  if (nbuckets * 4 >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   int cap0 = 64;
   while (cap0 < 4 * O) cap0 <<= 1;
   const size_t arena_cap = (size_t)N * cap0 + (size_t)N * 320 + 65536;
   if (arena_cap >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
-  if (w.n_pix < (size_t)N || w.n_rec < NL || w.n_cls_floats < (size_t)N * C || w.hcap < hcap ||
+  const size_t ovf_cap = NL / 256 + 4096;
+  if (w.n_pix < (size_t)N || w.n_rec < NL || w.n_cls_floats < (size_t)N * C || w.hcap < nbuckets ||
       w.arena_cap < arena_cap || w.leaf_cap < leaf_cap) {
     x_free(c);
     XState& X = w.X;
-    MN_HIP(x_alloc(c, &X.rkey, NL));
-    MN_HIP(x_alloc(c, &X.roml, NL));
+    MN_HIP(x_alloc(c, &X.rec, NL));
     MN_HIP(x_alloc(c, &X.leaf, leaf_cap));
-    MN_HIP(x_alloc(c, &X.rslot, NL));
-    MN_HIP(x_alloc(c, &X.hs, hcap));
-    MN_HIP(x_alloc(c, &X.lp, (size_t)N * C));
-    MN_HIP(x_alloc(c, &X.aptr, (size_t)N));
-    MN_HIP(x_alloc(c, &X.alen, (size_t)N));
+    MN_HIP(x_alloc(c, &X.hs, nbuckets * 4));
+    MN_HIP(x_alloc(c, &X.obj, (size_t)N));
     MN_HIP(x_alloc(c, &X.acap, (size_t)N));
+    MN_HIP(x_alloc(c, &X.lp, (size_t)N * C + 64));
     MN_HIP(x_alloc(c, &X.arena, arena_cap));
+    MN_HIP(x_alloc(c, &X.overflow, ovf_cap));
     MN_HIP(x_alloc(c, &X.l1g, (size_t)MN_X_MAXBLOCKS));
     MN_HIP(x_alloc(c, &X.ctl, 1));
     MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), sizeof(XCtl)));
-    w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = hcap; w.arena_cap = arena_cap;
+    w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = nbuckets; w.arena_cap = arena_cap;
     w.leaf_cap = leaf_cap;
+    X.overflow_cap = (int)ovf_cap;
   }
   XState& X = w.X;
-  X.hmask = (unsigned)(hcap - 1);
+  X.bmask = (unsigned)(nbuckets - 1);
   X.arena_cap = arena_cap;
   X.Blog = 0;
   while (((size_t)1 << X.Blog) < B) X.Blog++;
@@ -228,7 +229,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   X.NG = X.NBpad / 64;
   X.NL = (unsigned)NL;
   X.cap0 = cap0;
-  X.osize = c->osize; X.ocls = c->ocls; X.parent = c->parent;
+  X.parent = c->parent;
   return MN_OK;
 }
 
@@ -860,20 +861,21 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   mn_context::XWork& w = c->xw;
   XState& X = w.X;
   const size_t N = (size_t)P.N;
-  MN_HIP(hipMemsetAsync(X.hs, 0xFF, ((size_t)X.hmask + 1) * sizeof(XSlot), st));
+  MN_HIP(hipMemsetAsync(X.hs, 0xFF, ((size_t)X.bmask + 1) * 4 * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.arena, 0xFF, N * (size_t)X.cap0 * sizeof(unsigned), st));
-  MN_HIP(hipMemsetAsync(X.leaf, 0, ((size_t)X.NB << X.Blog) * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.leaf, 0, (((size_t)X.NB << X.Blog) + 1024) * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
   w.h_ctl->bump = (unsigned long long)N * (unsigned long long)X.cap0;
   MN_HIP(hipMemcpyAsync(X.ctl, w.h_ctl, sizeof(XCtl), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(mn_x_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->cls0);
   MN_HIP(hipEventRecord(c->ev[1], st));
   hipLaunchKernelGGL(mn_x_init_records, dim3(grid_for((size_t)X.NL, 256)), dim3(256), 0, st, P, X);
+  hipLaunchKernelGGL(mn_x_place_overflow, dim3(1), dim3(64), 0, st, X);
   MN_HIP(hipEventRecord(c->ev[2], st));
-  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 256 * 4 + 64;
+  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + 64;
   if (!w.lds_ready) {
     MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
     w.lds_ready = 1;
   }
   // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per record
@@ -907,11 +909,22 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   }
   if (w.h_ctl->status != MN_X_DONE) return MN_ERR_INTERNAL;
   if (getenv("MN_TRACE_EXACT"))
-    fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld probes %lld arena %llu of %llu\n",
+    fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld slow inserts %lld set-up overflow %d arena %llu of %llu\n",
             w.h_ctl->steps, w.h_ctl->merges, w.h_ctl->rescans, w.h_ctl->reallocs, w.h_ctl->folded,
-            w.h_ctl->adopted, w.h_ctl->probes, w.h_ctl->bump, X.arena_cap);
+            w.h_ctl->adopted, w.h_ctl->slow_inserts, w.h_ctl->n_overflow, w.h_ctl->bump, X.arena_cap);
+#ifdef MN_X_STAMPS
+  if (getenv("MN_TRACE_EXACT")) {
+    static const char* nm[12] = {"loop", "pop", "record+scan", "objects+score", "restale", "merge-state", "realloc",
+                                 "walk-load", "probe+third", "fold/adopt", "rescore+queue", "rescan+groups"};
+    long long tot = 0;
+    for (int i = 0; i < 12; i++) tot += w.h_ctl->stamps[i];
+    for (int i = 0; i < 12; i++)
+      fprintf(stderr, "  stamp %-14s %12lld cycles %5.1f%%\n", nm[i], w.h_ctl->stamps[i], 100.0 * w.h_ctl->stamps[i] / (tot ? tot : 1));
+  }
+#endif
   // what the output stage reads: class sums of the survivors (plane-major), step counters
-  hipLaunchKernelGGL(mn_x_export_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->lpsum, c->lpvalid);
+  hipLaunchKernelGGL(mn_x_export_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->osize, c->ocls,
+                     c->lpsum, c->lpvalid);
   const long long steps = w.h_ctl->steps, merges = w.h_ctl->merges;
   Counters hc;
   memset(&hc, 0, sizeof(hc));

@@ -14,10 +14,13 @@
 //               update touches the leaf, the block maximum and its group; a block is re-read from HBM
 //               only when its maximum was lowered or removed (the popped block always: read beside
 //               the step's other loads)
-//   * records = flat arrays indexed by record id = pixel * O + offset index (the reference's creation
-//               order, segment.cc:209-231): key (object pair), float32 log-odds sum, hash slot
-//   * pair -> record: one open-addressing table over (min id, max id) keys (the reference keeps a
-//               hash map per object, segment.h:136): fold look-ups of a merge run in parallel lanes
+//   * records = one 16-byte entry per record id = pixel * O + offset index (the reference's creation
+//               order, segment.cc:209-231): key (object pair), float32 log-odds sum, table slot
+//   * pair -> record: one cuckoo table over (min id, max id) keys, two buckets of four 16-byte slots
+//               per key (the reference keeps a hash map per object, segment.h:136): a look-up is two
+//               64-byte reads in flight together, whatever the history of the table; a delete frees its
+//               slot (no tombstones: the first version's linear probing spent 4 us per merge walking
+//               them); the fold look-ups of a merge run in parallel lanes
 //   * adjacency = one contiguous array of record ids per object in an arena; a merge walks ONLY the
 //               absorbed object's array (64 records per pass) and appends the re-keyed records to the
 //               survivor's (doubling reallocation, dead entries dropped on the way)
@@ -34,7 +37,6 @@
 
 #define MN_X_INVALID 0xFFFFFFFFu
 #define MN_X_HEMPTY 0xFFFFFFFFFFFFFFFFull
-#define MN_X_HTOMB 0xFFFFFFFFFFFFFFFEull
 #define MN_X_DIRTY 0xFFFFFFFFFFFFFFFFull
 #define MN_X_MAXBLOCKS 16384
 
@@ -42,39 +44,48 @@ enum { MN_X_RUNNING = 0, MN_X_DONE = 1, MN_X_BUDGET = 2, MN_X_ARENA_FULL = 3, MN
 
 struct XCtl {
   int status;                 // MN_X_*; < 0: mn_status error
-  int pad;
-  long long steps, merges, rescans, reallocs, folded, adopted, probes;
+  int n_overflow;             // records the parallel set-up could not place in the pair table
+  long long steps, merges, rescans, reallocs, folded, adopted, slow_inserts;
   unsigned long long bump;    // next free arena entry
+  long long stamps[16];       // -DMN_X_STAMPS (diagnostic build): cycles per phase of the loop
+};
+
+// one record (AdjacencyRecord, segment.h:175-232): ONE 16-byte load
+struct __attribute__((aligned(16))) XRec {
+  u64 key;                    // (lower object id << 32) | higher; MN_EMPTY = dead / never existed
+  float S;                    // obj_merge_logprob (float32, segment.cc:36, 690)
+  unsigned slot;              // slot of the key in the pair table
 };
 
 // one slot of the pair table: key, the record that carries it, and a copy of its log-odds sum (a fold
-// then needs no further round trip for the sum; roml[] keeps the copy the pop reads)
+// then needs no further round trip for the sum)
 struct __attribute__((aligned(16))) XSlot {
   u64 key;
   unsigned rid;
   float S;
 };
 
+// one object (Object, segment.h:85-137)
+struct __attribute__((aligned(16))) XObj {
+  int size;
+  int cls;
+  unsigned aptr;              // adjacency array: first arena entry
+  int alen;                   //                  entries in use (dead ones included)
+};
+
 struct XState {
-  // records, indexed by record id (pixel * O + k)
-  u64* rkey;                  // (lower object id << 32) | higher; MN_EMPTY = dead / never existed
-  float* roml;                // AdjacencyRecord::obj_merge_logprob (float32, segment.cc:36, 690)
-  unsigned* leaf;             // queue word of the stored priority: 0 = not queued
-  unsigned* rslot;            // slot of the record's key in the pair table
-  // pair table: 16-byte slots
-  XSlot* hs;
-  unsigned hmask;
-  // objects
+  XRec* rec;                  // [NL] indexed by record id (pixel * O + k)
+  unsigned* leaf;             // [NB << Blog] queue word of the stored priority: 0 = not queued
+  XSlot* hs;                  // pair table: (bmask + 1) buckets of 4 slots
+  unsigned bmask;
+  XObj* obj;                  // [N]
+  int* acap;                  // [N] adjacency entries owned
   float* lp;                  // [N][C] Object::class_logprobs (float32 sums, segment.cc:640)
-  int* osize;
-  unsigned char* ocls;
-  int* parent;
-  unsigned* aptr;             // adjacency array: first arena entry
-  int* alen;                  //                  entries in use (dead ones included)
-  int* acap;                  //                  entries owned
+  int* parent;                // [N] absorbed -> survivor (the context's union forest)
   unsigned* arena;
   unsigned long long arena_cap;
-  // queue
+  unsigned* overflow;         // record ids the set-up kernel could not place (both buckets full)
+  int overflow_cap;
   u64* l1g;                   // block maxima in HBM (built by mn_x_build_l1, loaded into LDS)
   int Blog, NB, NBpad, NG;
   unsigned NL;                // record ids in use (N * O)
@@ -141,14 +152,22 @@ __device__ __forceinline__ unsigned mn_x_rid(u64 e) { return 0xFFFFFFFFu - (unsi
 // Wave-wide reductions on the VALU (DPP row moves + four readlanes; a ds_bpermute-based __shfl_xor
 // costs an LDS round trip per step, and this loop does several reductions per step).  All lanes get
 // the result.
+#define MN_X_DPP4(OP, v)                                                                              \
+  v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));             \
+  v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));             \
+  v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));            \
+  v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
 __device__ __forceinline__ unsigned mn_x_wmax_u32(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+  MN_X_DPP4(max, v)
   const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
   const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
   return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ unsigned mn_x_wmin_u32(unsigned v) {
+  MN_X_DPP4(min, v)
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
 }
 __device__ __forceinline__ float mn_x_wmax_f32(float v) {
   v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
@@ -170,18 +189,21 @@ __device__ __forceinline__ u64 mn_x_wmax_pair(u64 v) {
   return ((u64)mh << 32) | (u64)ml;
 }
 
-__device__ __forceinline__ u64 mn_x_shfl_xor(u64 v, int off) {
-  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off);
-  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
-  return ((u64)hi << 32) | lo;
+__device__ __forceinline__ u64 mn_hash64(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
 }
-__device__ __forceinline__ u64 mn_x_wave_max(u64 v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const u64 o = mn_x_shfl_xor(v, off);
-    v = o > v ? o : v;
-  }
-  return v;
+// the two buckets of a key
+__device__ __forceinline__ void mn_x_buckets(u64 key, unsigned bmask, unsigned* b1, unsigned* b2) {
+  const u64 h = mn_hash64(key);
+  const unsigned x = (unsigned)h & bmask;
+  unsigned y = (unsigned)(h >> 32) & bmask;
+  if (y == x) y = (y ^ 1u) & bmask;
+  *b1 = x; *b2 = y;
 }
 
 // priority of the record (a, b), a < b by id, by ONE lane (ComputeClassDeltaLogprob +
@@ -218,31 +240,32 @@ __device__ __forceinline__ float mn_x_score1(const ImgParams& P, const float* la
   return (S * P.omf + cdl) / den + P.bias;
 }
 
-// The same priority for a record between the survivor of a merge (class vector `lpa` in LDS, class
-// `ca`, `na` pixels) and a third object (vector `l3` in HBM): the joint vector is symmetric, only the
-// order of the two subtractions follows the ids (a_first: the survivor has the lower id).
-__device__ __forceinline__ float mn_x_score_fold(const ImgParams& P, const float* lpa, const float* l3,
-                                                 int ca, int c3cls, int na, int n3, float S, bool a_first) {
-  float cdl = 0.0f;
-  if (ca != c3cls) {
-    const float la_c = lpa[ca], l3_c = l3[c3cls];
-    float bestv = 0.0f;
-    for (int c0 = 0; c0 < P.C; c0 += 16) {
-      float vb[16];
-#pragma unroll
-      for (int j = 0; j < 16; j++) vb[j] = (c0 + j < P.C) ? l3[c0 + j] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        if (c0 + j < P.C) {
-          const float v = a_first ? (lpa[c0 + j] + vb[j]) : (vb[j] + lpa[c0 + j]);
-          if ((c0 + j) == 0 || v > bestv) bestv = v;
-        }
-      }
-    }
-    cdl = a_first ? ((bestv - la_c) - l3_c) : ((bestv - l3_c) - la_c);
+// Insertion by ONE lane with everything read afresh (the rare paths: a record the parallel set-up could
+// not place, or a lane of a merge pass that lost its slot to another lane): a free slot of either
+// bucket, else one occupant is moved to ITS other bucket.  Returns the slot, MN_X_INVALID if no room.
+__device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned bmask, u64 key, unsigned rid, float S) {
+  unsigned b1, b2;
+  mn_x_buckets(key, bmask, &b1, &b2);
+  XSlot ns; ns.key = key; ns.rid = rid; ns.S = S;
+  for (int t = 0; t < 8; t++) {
+    const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
+    if (hs[s].key == MN_X_HEMPTY) { hs[s] = ns; return s; }
   }
-  const float den = (float)((unsigned long long)na + (unsigned long long)n3);
-  return (S * P.omf + cdl) / den + P.bias;
+  for (int t = 0; t < 8; t++) {
+    const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
+    const XSlot v = hs[s];
+    unsigned v1, v2;
+    mn_x_buckets(v.key, bmask, &v1, &v2);
+    const unsigned alt = ((s >> 2) == v1) ? v2 : v1;
+    for (int q = 0; q < 4; q++)
+      if (hs[alt * 4 + q].key == MN_X_HEMPTY) {
+        hs[alt * 4 + q] = v;
+        rec[v.rid].slot = alt * 4 + q;
+        hs[s] = ns;
+        return s;
+      }
+  }
+  return MN_X_INVALID;
 }
 
 // ---- set-up (parallel, whole chip) -----------------------------------------------------------------
@@ -258,13 +281,12 @@ __global__ __launch_bounds__(256) void mn_x_init_objects(ImgParams P, XState X,
     X.lp[(size_t)p * P.C + c] = l;
     if (c == 0 || l > best) { best = l; bc = c; }
   }
-  X.osize[p] = 1;
-  X.ocls[p] = (unsigned char)bc;
-  cls0[p] = (unsigned char)bc;
-  X.parent[p] = p;
-  X.aptr[p] = (unsigned)p * (unsigned)X.cap0;
-  X.alen[p] = 2 * P.O;
+  XObj o;
+  o.size = 1; o.cls = bc; o.aptr = (unsigned)p * (unsigned)X.cap0; o.alen = 2 * P.O;
+  X.obj[p] = o;
   X.acap[p] = X.cap0;
+  X.parent[p] = p;
+  cls0[p] = (unsigned char)bc;
 }
 
 // AdjacencyRecord ctor + the constructor's loop (segment.cc:24-46, 209-231): one lane per
@@ -277,8 +299,10 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
   const unsigned rid = (unsigned)gid;
   const int r = p / P.W, c = p - r * P.W;
   const int rr = r + P.di[k], cc = c + P.dj[k];
+  XRec R;
+  R.key = MN_EMPTY; R.S = 0.0f; R.slot = MN_X_INVALID;
   if (rr < 0 || rr >= P.H || cc < 0 || cc >= P.W) {
-    X.rkey[rid] = MN_EMPTY;
+    X.rec[rid] = R;
     X.leaf[rid] = 0u;
     return;
   }
@@ -289,23 +313,42 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
   const float oml = same - diff;
   const int a = min(p, q), b = max(p, q);
   int mc;
-  const float pr = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.ocls[a], X.ocls[b],
+  const float pr = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.obj[a].cls, X.obj[b].cls,
                                1, 1, oml, &mc);
   const u64 key = mn_key(a, b);
-  X.rkey[rid] = key;
-  X.roml[rid] = oml;
-  X.leaf[rid] = mn_x_word(pr);
-  unsigned s = mn_hash(key) & X.hmask;
-  for (;;) {
-    const u64 old = atomicCAS(&X.hs[s].key, MN_X_HEMPTY, key);
-    if (old == MN_X_HEMPTY) break;
-    s = (s + 1) & X.hmask;
+  unsigned b1, b2;
+  mn_x_buckets(key, X.bmask, &b1, &b2);
+  unsigned slot = MN_X_INVALID;
+  for (int t = 0; t < 8 && slot == MN_X_INVALID; t++) {
+    const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
+    if (atomicCAS(&X.hs[s].key, MN_X_HEMPTY, key) == MN_X_HEMPTY) slot = s;
   }
-  X.hs[s].rid = rid;
-  X.hs[s].S = oml;
-  X.rslot[rid] = s;
+  if (slot != MN_X_INVALID) {
+    X.hs[slot].rid = rid;
+    X.hs[slot].S = oml;
+  } else {
+    const int i = atomicAdd(&X.ctl->n_overflow, 1);
+    if (i < X.overflow_cap) X.overflow[i] = rid;
+  }
+  R.key = key; R.S = oml; R.slot = slot;
+  X.rec[rid] = R;
+  X.leaf[rid] = mn_x_word(pr);
   X.arena[(size_t)p * X.cap0 + k] = rid;
   X.arena[(size_t)q * X.cap0 + P.O + k] = rid;
+}
+
+// the few records both of whose buckets were full when the set-up kernel came by: one lane, one by one
+__global__ __launch_bounds__(64) void mn_x_place_overflow(XState X) {
+  if (threadIdx.x != 0) return;
+  const int n = X.ctl->n_overflow;
+  if (n > X.overflow_cap) { X.ctl->status = MN_X_HASH_FULL; return; }
+  for (int i = 0; i < n; i++) {
+    const unsigned rid = X.overflow[i];
+    const XRec R = X.rec[rid];
+    const unsigned s = mn_x_insert_slow(X.hs, X.rec, X.bmask, R.key, rid, R.S);
+    if (s == MN_X_INVALID) { X.ctl->status = MN_X_HASH_FULL; return; }
+    X.rec[rid].slot = s;
+  }
 }
 
 // block maxima of the queue words
@@ -319,7 +362,7 @@ __global__ __launch_bounds__(64) void mn_x_build_l1(XState X) {
       const u64 e = mn_x_pack(X.leaf[base + i], base + i);
       m = e > m ? e : m;
     }
-  m = mn_x_wave_max(m);
+  m = mn_x_wmax_pair(m);
   if (threadIdx.x == 0) X.l1g[blk] = m;
 }
 
@@ -330,39 +373,67 @@ __global__ __launch_bounds__(64) void mn_x_build_l1(XState X) {
 // memory pipeline preserves per address; -DMN_X_PARANOID drains the vector-memory counter after every
 // pass and step (results compared equal with and without on every reference vector).
 #define MN_X_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Diagnostic build only (-DMN_X_STAMPS, tests/tools/gpu_exact.py prints them with MN_TRACE_EXACT=1):
+// cycles per phase of the loop, every phase ended by a drain of the memory counters so that a phase
+// owns its own round trips.  No stamp executes in the product build.
+#ifdef MN_X_STAMPS
+#define MN_X_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long _t = clock64(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
+#else
+#define MN_X_STAMP(k) do { } while (0)
+#endif
 #ifdef MN_X_PARANOID
 #define MN_X_MEM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
 #define MN_X_MEM_SYNC() asm volatile("" ::: "memory")
 #endif
 
-// maximum (word, lowest record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads.
-// Words first (one v_max per leaf), then the lowest record id among the holders of the maximum.
+// maximum (word, lowest record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads,
+// no branches: the words first (one v_max per leaf), then the lowest id among the holders of the
+// maximum.  The leaf array is padded by 1024 words, so that a block shorter than a round of loads reads
+// (and ignores) what follows it.
+struct __attribute__((packed, aligned(4))) mn_x_f4u { float x, y, z, w; };   // 16-byte load, 4-byte aligned
+
+template <bool WITH_REC>
 __device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned base, int B, unsigned skip,
-                                               int lane) {
-  unsigned best = 0u, bestid = MN_X_INVALID;
+                                               int lane, const XRec* recp, uint4* rec_out) {
+  unsigned best = 0u;
+  unsigned bestid = MN_X_INVALID;
   for (int i0 = 0; i0 < B; i0 += 1024) {
     uint4 w[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int i = i0 + j * 256 + lane * 4;
-      w[j] = (i < B) ? *reinterpret_cast<const uint4*>(leaf + base + i) : make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int j = 0; j < 4; j++)
+      w[j] = *reinterpret_cast<const uint4*>(leaf + base + (unsigned)(i0 + j * 256 + lane * 4));
+    // (the popped record's own entry: issued BEHIND the leaf loads, so that the wait for the leaves
+    //  does not wait for it and the two round trips overlap)
+    if (WITH_REC && i0 == 0) *rec_out = *reinterpret_cast<const uint4*>(recp);
+    unsigned m = 0u;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const unsigned id = base + (unsigned)(i0 + j * 256 + lane * 4);
-      if ((skip & ~3u) == id) {
-        const unsigned q = skip & 3u;
-        if (q == 0) w[j].x = 0u; else if (q == 1) w[j].y = 0u; else if (q == 2) w[j].z = 0u; else w[j].w = 0u;
-      }
-      // (descending ids, so that among equal words the lowest id is the one kept)
-      if (w[j].w > best || (w[j].w == best && id + 3 < bestid)) { best = w[j].w; bestid = id + 3; }
-      if (w[j].z > best || (w[j].z == best && id + 2 < bestid)) { best = w[j].z; bestid = id + 2; }
-      if (w[j].y > best || (w[j].y == best && id + 1 < bestid)) { best = w[j].y; bestid = id + 1; }
-      if (w[j].x > best || (w[j].x == best && id < bestid)) { best = w[j].x; bestid = id; }
+      const int i = i0 + j * 256 + lane * 4;
+      const unsigned id = base + (unsigned)i;
+      const bool in = i < B;
+      w[j].x = (in && id != skip) ? w[j].x : 0u;
+      w[j].y = (in && id + 1 != skip) ? w[j].y : 0u;
+      w[j].z = (in && id + 2 != skip) ? w[j].z : 0u;
+      w[j].w = (in && id + 3 != skip) ? w[j].w : 0u;
+      m = max(max(m, w[j].x), max(max(w[j].y, w[j].z), w[j].w));
     }
+    // lowest id of this round holding its maximum (descending, so that the lowest wins)
+    unsigned mid = MN_X_INVALID;
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+      const unsigned id = base + (unsigned)(i0 + j * 256 + lane * 4);
+      mid = (w[j].w == m) ? id + 3 : mid;
+      mid = (w[j].z == m) ? id + 2 : mid;
+      mid = (w[j].y == m) ? id + 1 : mid;
+      mid = (w[j].x == m) ? id : mid;
+    }
+    if (m > best) { best = m; bestid = mid; }      // (later rounds hold higher ids: ties stay with the earlier)
   }
-  return mn_x_wmax_pair(mn_x_pack(best, bestid));
+  const unsigned mw = mn_x_wmax_u32(best);
+  if (mw == 0u) return 0ull;
+  const unsigned mi = mn_x_wmin_u32(best == mw ? bestid : MN_X_INVALID);
+  return mn_x_pack(mw, mi);
 }
 
 __device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int lane) {
@@ -375,8 +446,8 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
   u64* l1 = reinterpret_cast<u64*>(x_smem);                        // [NBpad]
   u64* l2 = l1 + X.NBpad;                                          // [NG]
   float* sh_lpa = reinterpret_cast<float*>(l2 + X.NG);             // [128] survivor's new class vector
-  unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups whose maxima changed
-  unsigned* sh_ctab = sh_gmask + 8;                                // [256] same-slot check of a pass's inserts
+  unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups that lost a maximum
+  unsigned* sh_ctab = sh_gmask + 8;                                // [2048] same-slot check of a pass's inserts
   const int lane = threadIdx.x;
   const int C = P.C;
   const int B = 1 << X.Blog;
@@ -387,11 +458,17 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
   for (int g = 0; g < X.NG; g++) mn_x_group_refresh(l1, l2, g, lane);
   MN_X_LDS_SYNC();
 
-  long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0;
+  long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0, slow_inserts = 0;
   unsigned long long bump = X.ctl->bump;
-  int status = MN_X_RUNNING;
+  int status = X.ctl->status < 0 || X.ctl->status == MN_X_HASH_FULL ? X.ctl->status : MN_X_RUNNING;
+#ifdef MN_X_STAMPS
+  long long st_acc[16];
+  for (int i = 0; i < 16; i++) st_acc[i] = 0;
+  long long st_last = clock64();
+#endif
 
-  for (;;) {
+  while (status == MN_X_RUNNING) {
+    MN_X_STAMP(0);
     // ---- pop: the largest (word, lowest record id) ----
     u64 top = 0;
     for (int g = lane; g < X.NG; g += 64) { const u64 v = l2[g]; top = v > top ? v : top; }
@@ -402,21 +479,24 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     if (steps >= budget) { status = MN_X_BUDGET; break; }
     const unsigned rid = mn_x_rid(top);
     const unsigned blk = rid >> X.Blog;
+    MN_X_STAMP(1);
     // the record, and beside it the popped block without it (its maximum changes either way)
-    const u64 key = X.rkey[rid];
-    const float S = X.roml[rid];
-    const unsigned slot_r = X.rslot[rid];
-    const u64 bm = mn_x_scan_block(X.leaf, blk << X.Blog, B, rid, lane);
+    uint4 rraw;
+    const u64 bm = mn_x_scan_block<true>(X.leaf, blk << X.Blog, B, rid, lane, &X.rec[rid], &rraw);
+    const u64 key = ((u64)rraw.y << 32) | (u64)rraw.x;
+    const float S = __uint_as_float(rraw.z);
+    const unsigned slot_r = rraw.w;
     if (key == MN_EMPTY) { status = MN_ERR_INTERNAL; break; }
+    MN_X_STAMP(2);
     const int x = mn_key_u(key), y = mn_key_v(key);
     // ---- re-score (segment.cc:560): both objects' state in one round trip ----
-    const int nx = X.osize[x], ny = X.osize[y];
-    const int cx = X.ocls[x], cy = X.ocls[y];
-    const unsigned ptrx = X.aptr[x], ptry = X.aptr[y];
-    const int lenx = X.alen[x], leny = X.alen[y], capx = X.acap[x], capy = X.acap[y];
+    const uint4 ox = *reinterpret_cast<const uint4*>(&X.obj[x]);
+    const uint4 oy = *reinterpret_cast<const uint4*>(&X.obj[y]);
+    const int capx = X.acap[x], capy = X.acap[y];
     float ax0 = 0.0f, ay0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f;
     if (lane < C) { ax0 = X.lp[(size_t)x * C + lane]; ay0 = X.lp[(size_t)y * C + lane]; }
     if (lane + 64 < C) { ax1 = X.lp[(size_t)x * C + lane + 64]; ay1 = X.lp[(size_t)y * C + lane + 64]; }
+    const int nx = (int)ox.x, ny = (int)oy.x, cx = (int)ox.y, cy = (int)oy.y;
     float cdl = 0.0f;
     int mc = cx;
     if (cx != cy) {
@@ -443,6 +523,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     const float f = (S * P.omf + cdl) / den + P.bias;
     const unsigned fw = mn_x_word(f);
     steps++;
+    MN_X_STAMP(3);
     if (fw != gword) {
       // ---- not what the queue promised: store the fresh value (segment.cc:563-565) ----
       if (lane == 0) {
@@ -453,16 +534,17 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       MN_X_LDS_SYNC();
       mn_x_group_refresh(l1, l2, (int)(blk >> 6), lane);
       MN_X_LDS_SYNC();
+      MN_X_STAMP(4);
       continue;
     }
 
     // ---- merge (segment.cc:602-727): the larger object survives, a tie keeps the lower id ----
     const bool swap = nx < ny;
     const int a = swap ? y : x, b = swap ? x : y;
-    unsigned pa = swap ? ptry : ptrx;
-    const unsigned pb = swap ? ptrx : ptry;
-    int la = swap ? leny : lenx;
-    const int lb = swap ? lenx : leny;
+    unsigned pa = swap ? oy.z : ox.z;
+    const unsigned pb = swap ? ox.z : oy.z;
+    int la = (int)(swap ? oy.w : ox.w);
+    const int lb = (int)(swap ? ox.w : oy.w);
     int capa = swap ? capy : capx;
     // room for the records the survivor may adopt; checked before anything is changed, so that a
     // full arena leaves a consistent state behind
@@ -482,16 +564,15 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     if (lane + 64 < C) { const float s1 = ax1 + ay1; X.lp[(size_t)a * C + lane + 64] = s1; sh_lpa[lane + 64] = s1; }
     const int na = nx + ny;
     if (lane == 0) {
-      X.osize[a] = na;
-      X.ocls[a] = (unsigned char)mc;
       X.parent[b] = a;
-      X.rkey[rid] = MN_EMPTY;                  // the merged record leaves every list (:645-647)
+      X.rec[rid].key = MN_EMPTY;               // the merged record leaves every list (:645-647)
       X.leaf[rid] = 0u;
-      X.hs[slot_r].key = MN_X_HTOMB;
+      X.hs[slot_r].key = MN_X_HEMPTY;
       l1[blk] = bm;
       sh_gmask[blk >> 11] |= 1u << ((blk >> 6) & 31u);
     }
     MN_X_LDS_SYNC();
+    MN_X_STAMP(5);
     if (moved) {
       // the survivor's live entries move to a larger array
       int cnt = 0;
@@ -499,16 +580,17 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         const int j = j0 + lane;
         unsigned e = (j < la) ? X.arena[(size_t)pa + j] : MN_X_INVALID;
         bool live = e != MN_X_INVALID && e != rid;
-        if (live) live = X.rkey[e] != MN_EMPTY;
+        if (live) live = X.rec[e].key != MN_EMPTY;
         const u64 mk = __ballot(live);
         if (live) X.arena[(size_t)newp + cnt + __popcll(mk & ((1ull << lane) - 1ull))] = e;
         cnt += __popcll(mk);
       }
       pa = newp; la = cnt; capa = newcap;
       reallocs++;
-      if (lane == 0) { X.aptr[a] = pa; X.acap[a] = capa; }
+      if (lane == 0) X.acap[a] = capa;
     }
     const float la_c = sh_lpa[mc];
+    MN_X_STAMP(6);
     // ---- the absorbed object's records (:650-707), 64 per pass ----
     for (int j0 = 0; j0 < lb; j0 += 64) {
       const int j = j0 + lane;
@@ -517,11 +599,15 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       u64 kt = MN_EMPTY;
       float St = 0.0f;
       unsigned slot_t = 0;
-      if (live) { kt = X.rkey[e]; St = X.roml[e]; slot_t = X.rslot[e]; }
+      if (live) {
+        const uint4 t = *reinterpret_cast<const uint4*>(&X.rec[e]);
+        kt = ((u64)t.y << 32) | (u64)t.x; St = __uint_as_float(t.z); slot_t = t.w;
+      }
       live = live && kt != MN_EMPTY;
+      MN_X_STAMP(7);
       const int c3 = live ? ((mn_key_u(kt) == b) ? mn_key_v(kt) : mn_key_u(kt)) : 0;
-      // ONE round trip: the third object's state (its first sixteen class terms included) and the
-      // first slot of the table look-up of (survivor, third)
+      // ONE round trip: the third object's state (its first sixteen class terms included) and both
+      // buckets of (survivor, third) in the pair table
       int n3 = 0, cc3 = 0;
       u64 key2 = 0;
       int found = -1, freeslot = -1;
@@ -530,26 +616,34 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       float v3[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) v3[q] = 0.0f;
-      bool hfull = false;
       if (live) {
         const float* l3 = X.lp + (size_t)c3 * C;
-        n3 = X.osize[c3];
-        cc3 = X.ocls[c3];
+        const uint4 o3 = *reinterpret_cast<const uint4*>(&X.obj[c3]);
 #pragma unroll
-        for (int q = 0; q < 16; q++) if (q < C) v3[q] = l3[q];
+        for (int q = 0; q < 4; q++)
+          if (4 * q < C) {     // (16-byte loads; what lies behind the object's C terms is read and ignored)
+            const mn_x_f4u t = *reinterpret_cast<const mn_x_f4u*>(l3 + 4 * q);
+            v3[4 * q] = t.x; v3[4 * q + 1] = t.y; v3[4 * q + 2] = t.z; v3[4 * q + 3] = t.w;
+          }
         key2 = mn_key(a, c3);
-        unsigned s = mn_hash(key2) & X.hmask;
-        for (int guard = 0;; guard++) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(&X.hs[s]);
-          const u64 hk = ((u64)raw.y << 32) | (u64)raw.x;
-          if (hk == key2) { found = (int)s; u_rid = raw.z; Su = __uint_as_float(raw.w); break; }
-          if (hk == MN_X_HEMPTY) { if (freeslot < 0) freeslot = (int)s; break; }
-          if (hk == MN_X_HTOMB && freeslot < 0) freeslot = (int)s;
-          s = (s + 1) & X.hmask;
-          if (guard > (1 << 22)) { hfull = true; break; }
+        unsigned b1, b2;
+        mn_x_buckets(key2, X.bmask, &b1, &b2);
+        uint4 sl[8];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          sl[t] = *reinterpret_cast<const uint4*>(&X.hs[b1 * 4 + t]);
+          sl[4 + t] = *reinterpret_cast<const uint4*>(&X.hs[b2 * 4 + t]);
+        }
+        n3 = (int)o3.x; cc3 = (int)o3.y;
+#pragma unroll
+        for (int t = 7; t >= 0; t--) {
+          const u64 hk = ((u64)sl[t].y << 32) | (u64)sl[t].x;
+          const int sidx = (int)((t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4));
+          if (hk == key2) { found = sidx; u_rid = sl[t].z; Su = __uint_as_float(sl[t].w); }
+          if (hk == MN_X_HEMPTY) freeslot = sidx;
         }
       }
-      if (__ballot(hfull)) { status = MN_X_HASH_FULL; break; }
+      MN_X_STAMP(8);
       unsigned tr = MN_X_INVALID;   // the record this lane re-scores
       float Sn = St;
       const bool fold = live && found >= 0;
@@ -558,49 +652,45 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         // the survivor already has a record with the third object: add (:690-692), retire this one (:694)
         tr = u_rid;
         Sn = Su + St;
-        X.roml[tr] = Sn;
+        X.rec[tr].S = Sn;
         X.hs[found].S = Sn;
-        X.rkey[e] = MN_EMPTY;
+        X.rec[e].key = MN_EMPTY;
         X.leaf[e] = 0u;
-        X.hs[slot_t].key = MN_X_HTOMB;
+        X.hs[slot_t].key = MN_X_HEMPTY;
       }
       const u64 am = __ballot(adopt);
       if (am) {
         // re-key (:659-664, 677), adopt into the survivor's list (:700-702).  Two lanes of a pass may
-        // have found the same free slot: the first writer of a 256-entry LDS tag keeps it, the others
-        // look again one after the other (rare)
-        if (adopt) sh_ctab[(unsigned)freeslot & 255u] = (unsigned)lane;
+        // have chosen the same free slot (or a lane found no free slot): the first writer of a
+        // 2048-entry LDS tag keeps its slot, the others insert one after the other with fresh reads
+        const unsigned tag = ((unsigned)freeslot ^ ((unsigned)freeslot >> 11)) & 2047u;
+        if (adopt && freeslot >= 0) sh_ctab[tag] = (unsigned)lane;
         MN_X_LDS_SYNC();
-        const bool clash = adopt && sh_ctab[(unsigned)freeslot & 255u] != (unsigned)lane;
+        const bool clash = adopt && (freeslot < 0 || sh_ctab[tag] != (unsigned)lane);
+        unsigned nslot = (unsigned)freeslot;
         if (adopt) {
           tr = e;
-          X.rkey[e] = key2;
-          X.hs[slot_t].key = MN_X_HTOMB;
+          X.hs[slot_t].key = MN_X_HEMPTY;
           X.arena[(size_t)pa + la + __popcll(am & ((1ull << lane) - 1ull))] = e;
         }
         if (adopt && !clash) {
           XSlot ns; ns.key = key2; ns.rid = e; ns.S = St;
           *reinterpret_cast<uint4*>(&X.hs[freeslot]) = *reinterpret_cast<const uint4*>(&ns);
-          X.rslot[e] = (unsigned)freeslot;
         }
         u64 cm = __ballot(clash);
         while (cm) {
           const int l = __ffsll((long long)cm) - 1;
           cm &= cm - 1ull;
-          if (lane == l) {
-            unsigned s = mn_hash(key2) & X.hmask;
-            for (int guard = 0; guard < (1 << 22); guard++) {
-              const u64 hk = X.hs[s].key;
-              if (hk == MN_X_HEMPTY || hk == MN_X_HTOMB) break;
-              s = (s + 1) & X.hmask;
-            }
-            XSlot ns; ns.key = key2; ns.rid = e; ns.S = St;
-            *reinterpret_cast<uint4*>(&X.hs[s]) = *reinterpret_cast<const uint4*>(&ns);
-            X.rslot[e] = s;
-          }
-          MN_X_MEM_SYNC();
+          slow_inserts++;
+          if (lane == l) nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St);
+        }
+        if (__ballot(adopt && nslot == MN_X_INVALID)) { status = MN_X_HASH_FULL; break; }
+        if (adopt) {
+          XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
+          *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
         }
       }
+      MN_X_STAMP(9);
       la += __popcll(am);
       adopted += __popcll(am);
       folded += __popcll(__ballot(fold));
@@ -610,7 +700,13 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         float cdl3 = 0.0f;
         if (mc != cc3) {
           const float* l3 = X.lp + (size_t)c3 * C;
-          const float l3_c = l3[cc3];
+          float l3_c = 0.0f;
+          if (cc3 < 16) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) l3_c = (q == cc3) ? v3[q] : l3_c;
+          } else {
+            l3_c = l3[cc3];
+          }
           float bestv = 0.0f;
 #pragma unroll
           for (int q = 0; q < 16; q++)
@@ -629,29 +725,39 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         w = mn_x_word((Sn * P.omf + cdl3) / den3 + P.bias);
         X.leaf[tr] = w;
       }
-      // ---- queue: block maxima of the retired and the re-scored records; a block whose maximum was
-      //      lowered or removed is marked and re-read at the end of the step ----
+      // ---- queue: a raised or new value goes into the block and group maxima by LDS atomics; a block
+      //      whose maximum was lowered or removed is marked, and re-read at the end of the step ----
       if (fold) {
         const unsigned be = e >> X.Blog;
         const u64 cur = l1[be];
-        if (cur != 0ull && mn_x_rid(cur) == e) atomicMax(&l1[be], MN_X_DIRTY);
-        atomicOr(&sh_gmask[be >> 11], 1u << ((be >> 6) & 31u));
+        if (cur != 0ull && mn_x_rid(cur) == e) {
+          atomicMax(&l1[be], MN_X_DIRTY);
+          atomicOr(&sh_gmask[be >> 11], 1u << ((be >> 6) & 31u));
+        }
       }
       if (live) {
         const unsigned bt = tr >> X.Blog;
         const u64 cur = l1[bt];
         const u64 ne = mn_x_pack(w, tr);
-        if (cur != 0ull && cur != MN_X_DIRTY && mn_x_rid(cur) == tr && ne < cur) atomicMax(&l1[bt], MN_X_DIRTY);
-        else if (ne) atomicMax(&l1[bt], ne);
-        atomicOr(&sh_gmask[bt >> 11], 1u << ((bt >> 6) & 31u));
+        if (cur != 0ull && cur != MN_X_DIRTY && mn_x_rid(cur) == tr && ne < cur) {
+          atomicMax(&l1[bt], MN_X_DIRTY);
+          atomicOr(&sh_gmask[bt >> 11], 1u << ((bt >> 6) & 31u));
+        } else if (ne) {
+          atomicMax(&l1[bt], ne);
+          atomicMax(&l2[bt >> 6], ne);
+        }
       }
       MN_X_LDS_SYNC();
       MN_X_MEM_SYNC();   // (paranoid build: this pass's stores before the next pass's loads)
+      MN_X_STAMP(10);
     }
     if (status != MN_X_RUNNING) break;
-    if (lane == 0) X.alen[a] = la;
+    if (lane == 0) {
+      XObj o; o.size = na; o.cls = mc; o.aptr = pa; o.alen = la;
+      X.obj[a] = o;
+    }
     MN_X_MEM_SYNC();
-    // ---- re-read the blocks whose maximum was lowered or removed, then the groups ----
+    // ---- re-read the blocks whose maximum was lowered or removed, then their groups ----
     for (int wd = 0; wd < 8; wd++) {
       unsigned m = sh_gmask[wd];
       while (m) {
@@ -662,7 +768,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
         while (dm) {
           const unsigned bb = (unsigned)(g * 64 + __ffsll((long long)dm) - 1);
           dm &= dm - 1ull;
-          const u64 v = mn_x_scan_block(X.leaf, bb << X.Blog, B, MN_X_INVALID, lane);
+          const u64 v = mn_x_scan_block<false>(X.leaf, bb << X.Blog, B, MN_X_INVALID, lane, nullptr, nullptr);
           if (lane == 0) l1[bb] = v;
           rescans++;
         }
@@ -673,24 +779,33 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     MN_X_LDS_SYNC();
     if (lane < 8) sh_gmask[lane] = 0u;
     MN_X_LDS_SYNC();
+    MN_X_STAMP(11);
   }
 
   if (lane == 0) {
     XCtl* c = X.ctl;
+#ifdef MN_X_STAMPS
+    for (int i = 0; i < 16; i++) c->stamps[i] += st_acc[i];
+#endif
     c->status = status;
     c->steps += steps; c->merges += merges; c->rescans += rescans; c->reallocs += reallocs;
-    c->folded += folded; c->adopted += adopted;
+    c->folded += folded; c->adopted += adopted; c->slow_inserts += slow_inserts;
     c->bump = bump;
   }
 }
 
 // ---- hand-over to the output stage -------------------------------------------------------------------
-// The output kernels read the class sums of live objects from the plane-major table (mn_obj_lp):
-// copy the survivors' vectors there.
-__global__ __launch_bounds__(256) void mn_x_export_objects(ImgParams P, XState X, float* __restrict__ lpsum,
+// The output kernels read object sizes, classes and the class sums of live objects (plane-major table,
+// mn_obj_lp) from the context's own arrays: copy the survivors' state there.
+__global__ __launch_bounds__(256) void mn_x_export_objects(ImgParams P, XState X, int* __restrict__ osize,
+                                                           unsigned char* __restrict__ ocls,
+                                                           float* __restrict__ lpsum,
                                                            unsigned char* __restrict__ lpvalid) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.N) return;
+  const XObj o = X.obj[p];
+  osize[p] = o.size;
+  ocls[p] = (unsigned char)o.cls;
   const bool root = X.parent[p] == p;
   lpvalid[p] = root ? 1 : 0;
   if (!root) return;
@@ -702,12 +817,13 @@ __global__ __launch_bounds__(256) void mn_x_export_objects(ImgParams P, XState X
 __global__ __launch_bounds__(256) void mn_x_verify_records(ImgParams P, XState X, int* __restrict__ violations) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= X.NL) return;
-  const u64 key = X.rkey[i];
-  if (key == MN_EMPTY) return;
-  const int a = mn_key_u(key), b = mn_key_v(key);
+  const XRec R = X.rec[i];
+  if (R.key == MN_EMPTY) return;
+  const int a = mn_key_u(R.key), b = mn_key_v(R.key);
+  const XObj oa = X.obj[a], ob = X.obj[b];
   int mc;
-  const float f = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.ocls[a], X.ocls[b],
-                              X.osize[a], X.osize[b], X.roml[i], &mc);
+  const float f = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, oa.cls, ob.cls,
+                              oa.size, ob.size, R.S, &mc);
   const float margin = 1e-6f + 1e-5f * fabsf(P.bias);
   if (!(f < -margin)) atomicAdd(violations + 4, 1);
 }
