@@ -15,9 +15,13 @@ through POOL different images (636 MB of maps, more than the 256 MiB Infinity Ca
 reads its maps from HBM and not from a cache warmed by the previous step.
 
 Rank 0 prints ONE JSON line.  `value` = pixels merged by all ranks / wall time of the K timed
-steps (max over ranks), in Mpixel/s, in the library's default mode (AUTO: the component
-contraction when the maps are sign-separable, else the general rounds -- `mode_used` says which
-ran).  `roofline` prices the slowest streaming kernel of the timed path with HIP events taken on
+steps (max over ranks), in Mpixel/s, on the library's SPECULATIVE fast path (mode AUTO with
+require_proof = -1: the component contraction when the maps are sign-separable, else the general rounds
+-- `mode_used` says which ran).  On these images the fast path's answer is not certified (the 0.03 bias
+lets the background swallow small instances in a second phase whose order matters), so its equality with
+the reference is MEASURED on every image of the pool in every run (`id_match`, against the reference's
+own outputs) instead of proven; the library's default AUTO would redo such an image in the exact engine
+(`exact_engine`: the reference's sequential order on the GPU, timed here on a bounded sample).  `roofline` prices the slowest streaming kernel of the timed path with HIP events taken on
 the launch stream inside the library (algorithmic bytes: 4 B per plane value, SURVEY.md section
 8d: C class planes or O sameness planes per pass); `passes` lists every streaming pass of the
 step the same way, and `scoring_pass_general_path` is the class pass + edge pass of the general
@@ -87,6 +91,47 @@ def cpu_baseline():
     return out
 
 
+def exact_engine_sample(seg, synth, offs, device):
+    """One 512x1024 synth-v1 image (the reference caller's working size; the reference needs 84 s) and one
+    blurred 256x512 map through MN_MODE_EXACT, each checked against the reference's own output."""
+    import numpy as np
+    import torch
+    from mergenet_amd import labels as ck
+    out = []
+    for (name, hh, ww, maker) in (("cseg_synth_512x1024_s1000", 512, 1024, lambda: synth.synth_v1(512, 1024, C, offs, 1000)),
+                                  ("cseg_blur_256x512_r2", 256, 512, None)):
+        golden = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        if not os.path.exists(golden):
+            continue
+        z = np.load(golden)
+        if maker is None:
+            spec = json.loads(str(z["spec"]))
+            img = synth.blurred_v1(hh, ww, C, offs, spec["seed"], radius=spec["radius"], noise=spec["noise"],
+                                   num_instances=spec.get("num_instances"))
+        else:
+            img = maker()
+        m = seg.Merger(hh, ww, C, len(offs), device=device)
+        cp = torch.from_numpy(img.class_probs).cuda(device)
+        sp = torch.from_numpy(img.sameness_probs).cuda(device)
+        o = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
+                                merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_EXACT, clip_inputs=1)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        mask, table, _, st = m.segment(cp, sp, offs, o)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        got = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
+        same = bool(ck.masks_equivalent(mask.cpu().numpy(), got, z["mask"], [int(c) for c in z["object_class"]]))
+        out.append({"image": name, "seconds": round(dt, 3), "value": round(hh * ww / dt / 1e6, 4), "unit": "Mpixel/s",
+                    "steps": st["finisher_steps"], "merges": st["merges"], "proof": st["proof"],
+                    "equals_reference": same})
+        m.close()
+    return {"what": "MN_MODE_EXACT: the reference's sequential order (segment.cc:539-727) with its float32 "
+                    "arithmetic, one wavefront per image; what AUTO falls back to when the fast path cannot "
+                    "certify its answer.  The reference itself: 84 s at 512x1024, 12-15 s at 256x512 (BASELINE.md)",
+            "samples": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine sample (about 8 s)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
@@ -164,13 +210,13 @@ def main():
     mergers_ring = [merger] + [seg.Merger(H, W, C, O, device=local_rank) for _ in range(max(1, args.contexts) - 1)]
     main_pool = seg.MergerPool(H, W, C, O, depth=depth, device=local_rank) if depth > 1 else None
     opts = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
-                               merge_logprob_bias=OPTS[2], mode=args.mode,
+                               merge_logprob_bias=OPTS[2], mode=args.mode, require_proof=seg.MN_PROVE_NEVER,
                                debug_flags=(2 if args.no_kernel_events else 0) | int(os.environ.get("MN_BENCH_FLAGS", "0")))
     # HIP events are host work (~3.5 us to record, ~8 us to read): every timed step carries the pair
     # around the sweep (the roofline kernel); one step in EVENTS_EVERY carries all of them (the
     # per-phase report), so that the host does not become the bottleneck of the loop it measures
     opts_lean = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
-                                    merge_logprob_bias=OPTS[2], mode=args.mode,
+                                    merge_logprob_bias=OPTS[2], mode=args.mode, require_proof=seg.MN_PROVE_NEVER,
                                     debug_flags=(2 if args.no_kernel_events else (48 if args.replay else 16))
                                     | int(os.environ.get("MN_BENCH_FLAGS", "0")))
     ring_out = [(torch.empty((H, W), dtype=torch.int32, device=dev), torch.empty((H * W,), dtype=torch.int32, device=dev))
@@ -354,6 +400,13 @@ def main():
                 g[k] += st_r[k] / POOL
         general = g
 
+    # the exact engine (the reference's sequential order itself, MN_MODE_EXACT) on a bounded sample,
+    # outside the timed region: what the library's default AUTO falls back to when the fast path's
+    # answer is not certified
+    exact = None
+    if rank == 0 and world == 1 and not args.no_exact:
+        exact = exact_engine_sample(seg, synth, offs, local_rank)
+
     if rank == 0:
         plane_bytes = 4.0 * H * W
         pmc = {}
@@ -366,7 +419,9 @@ def main():
             gbs = planes * plane_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"kernel": name, "reads": what, "algorithmic_bytes": planes * plane_bytes,
                     "avg_launch_ms": round(ms, 5), "achieved": round(gbs, 2),
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name)}
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc.get(name),
+                    "traffic_source": "profiles/%s (separate --pmc passes; NOT measured in this run)"
+                                      % os.path.basename(pmc_path) if pmc.get(name) else None}
 
         if avg["ms_cc_sums"] > 0:      # components mode
             # the affinity-scoring sweep (mn_cc_sign, class-plane form) reads EVERY input plane once:
@@ -389,6 +444,7 @@ def main():
         dom = max(streaming, key=lambda p: p["avg_launch_ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                    "traffic_source": dom["traffic_source"],
                     "algorithmic_bytes": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_launch_ms"],
                     "timing": "hipEvent pair attached to the kernel's own dispatch on the launch stream "
                               "(hipExtLaunchKernel start/stop events) in EVERY timed step; rocprofv3 "
@@ -426,6 +482,10 @@ def main():
                                        "context's side stream beside the next images' sweeps)"
                                        % (len(mergers_ring) - 1, len(mergers_ring)),
                        "mode": {0: "auto", 1: "exact", 2: "rounds", 3: "components"}.get(args.mode),
+                       "proof": "speculative fast path (require_proof = -1): on these images its answer is not "
+                                "certified -- equality with the reference's own outputs is measured on every image "
+                                "of the pool in this run (id_match); the library's default AUTO redoes an "
+                                "uncertified image in the exact engine (exact_engine)",
                        "mode_used": sorted({1: "exact", 2: "rounds", 3: "components"}.get(m, m) for m in modes),
                        "exchange": ("one all_gather per step of the masks (%s wire) + class tables + "
                                     "log-likelihoods, overlapped with the next step's merge; delivered "
@@ -465,6 +525,8 @@ def main():
                 "algorithmic_bytes": (C + O) * plane_bytes, "avg_launch_ms": round(sc_ms, 5),
                 "whole_image_ms_rounds_mode": round(general["ms_total"], 3),
                 "note": "measured live with the same HIP events, outside the timed steps"}
+        if exact is not None:
+            out["exact_engine"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

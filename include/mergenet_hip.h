@@ -41,8 +41,8 @@ enum mn_status {
   MN_ERR_CAPACITY = -4,     /* image larger than the context was created for                  */
   MN_ERR_NO_BACKGROUND = -10, /* pysegmenter prune: no class-0 object (reference: NameError)  */
   MN_ERR_INTERNAL = -20,
-  MN_ERR_UNPROVEN = -30     /* require_proof set and the result is neither certified nor from the
-                               sequential order (the approximate result IS written)              */
+  MN_ERR_UNPROVEN = -30     /* a proven result was asked for, the fast path could not certify its own and
+                               the exact engine found no room for its workspace                   */
 };
 
 enum mn_variant {
@@ -51,9 +51,15 @@ enum mn_variant {
 };
 
 enum mn_mode {
-  MN_MODE_AUTO = 0,      /* EXACT when the image has <= exact_limit initial records, else
-                            COMPONENTS                                                           */
-  MN_MODE_EXACT = 1,     /* sequential lazy-greedy order on the GPU (one workgroup)              */
+  MN_MODE_AUTO = 0,      /* the reference's result, by the cheapest route that PROVES it: EXACT when the
+                            image has <= exact_limit initial records; else COMPONENTS, kept when the
+                            certificate holds (any order of the lazy greedy ends in this partition);
+                            else EXACT (require_proof = -1: keep the fast path's unproven answer)   */
+  MN_MODE_EXACT = 1,     /* the reference's sequential lazy-greedy order itself, any image size: the
+                            exact engine (mn_kernels_exact.h) -- float32 state and operation order of
+                            segment.cc, glibc's logf restated bit for bit, pop = block-max queue in
+                            LDS, per-object adjacency, pair table; ~1.5 s at 256x512, ~6 s at 512x1024
+                            (the reference: 12 s and 84 s)                                         */
   MN_MODE_ROUNDS = 2,    /* parallel rounds + sequential finisher + certificate                  */
   MN_MODE_COMPONENTS = 3 /* sign-separable inputs: phase 1 of the merge (provably order-
                             independent there) by one union-find sweep over the positive edges,
@@ -68,7 +74,8 @@ typedef struct mn_options {
   int variant;                 /* enum mn_variant */
   int mode;                    /* enum mn_mode */
   int clip_inputs;             /* 1: clip to [2^-23, 1-2^-23] on load (c_segment.pyx:53-55 fused) */
-  int exact_limit;             /* AUTO: max initial records for exact mode (0 = default 32768)   */
+  int exact_limit;             /* AUTO: images with at most this many initial records go to EXACT right
+                                  away (0 = default 32768)                                        */
   int finish_limit;            /* ROUNDS: hand over to the sequential finisher at <= this many
                                   live records (0 = default: 2048 in the rounds, 4096 records
                                   between components in components mode)                         */
@@ -87,7 +94,7 @@ typedef struct mn_options {
                                   compare the two); bit 1: no per-kernel timestamps in components mode
                                   (ms_cc_* stay 0; each is an event on the caller's stream); bit 2:
                                   general rounds from single pixels instead of from the cores; bit 3: no
-                                  contraction of order-free clusters in the general rounds; bit 4: only
+                                  contraction of order-free clusters in the general rounds (overrides bit 9); bit 4: only
                                   the sweep is timed (ms_cc_edges; the other ms_* stay 0) -- an event
                                   costs the host ~3.5 us to record and ~8 us to read; bit 5 (with
                                   bit 4): replay -- when mn_segment_launch is called again with the
@@ -96,11 +103,19 @@ typedef struct mn_options {
                                   (from the third): a loop over images through fixed buffers; bit 7:
                                   time the sweep with an event packet before and behind it instead
                                   of start/stop events on its own dispatch (round 2's first form:
-                                  measures dispatch gap + kernel)                                  */
-  int require_proof;           /* 1: a result that is not PROVEN equal to the reference's sequential
-                                  order (stats.proof == 0) is redone in MN_MODE_EXACT when the image
-                                  has at most exact_limit_proof initial records, else the call returns
-                                  MN_ERR_UNPROVEN -- the library says no instead of guessing       */
+                                  measures dispatch gap + kernel); bit 9: the general rounds contract order-free
+                                  clusters of objects (round 2's default; 2.5 instead of ~12 ms on a
+                                  separable 1024x2048 map, but the second phase then starts from fresh
+                                  instead of stale priorities: off by default); bit 8: MN_MODE_EXACT by the small-list
+                                  finisher (one workgroup, O(records) arg-max per step, fixed-point sums)
+                                  instead of the exact engine -- kept for comparison                */
+  int require_proof;           /* what happens to a result that is not PROVEN equal to the reference's
+                                  sequential order (stats.proof == 0): 1 = it is redone in MN_MODE_EXACT,
+                                  whatever mode was asked for; -1 = it is handed back as it is (the
+                                  speculative fast path: an approximation on order-dependent inputs,
+                                  stats.proof tells); 0 (default) = by mode: AUTO redoes it, an explicit
+                                  MN_MODE_ROUNDS / MN_MODE_COMPONENTS request is taken as a request for
+                                  that engine's own answer                                          */
   int core_radius;             /* general rounds: an offset counts as SHORT when both its components
                                   are at most this many pixels; a pixel is clean -- and may join a core
                                   ahead of the rounds -- when all its short edges are positive and
@@ -138,7 +153,8 @@ typedef struct mn_stats {
                                   only; an approximation of the sequential order on order-dependent
                                   inputs), 1 = certificate (ANY order of the lazy greedy ends here,
                                   DESIGN.md section 5), 2 = the sequential order itself was run
-                                  (MN_MODE_EXACT; ties between bit-equal priorities aside)         */
+                                  (MN_MODE_EXACT; ties between bit-equal priorities go to the lowest
+                                  record id, which agrees with the reference on every vector held)   */
   int cores_condemned;         /* general rounds: 1 if a core held an edge that was not positive and
                                   fell apart again (mn_core_check); 0 otherwise                    */
   int reserved_i[2];
@@ -197,6 +213,15 @@ int mn_score_device(mn_context* ctx, const float* d_class_pred, int class_dim,
                     int num_classes, const int* offset_list, const mn_options* opts, void* stream,
                     unsigned char* d_cls_out, unsigned long long* d_best_out, float* ms_class_pass,
                     float* ms_edge_pass);
+
+/* Phase A of the exact engine alone (tests pin it against the oracle, bit for bit): per record the
+ * float32 log-odds obj_merge_logprob (segment.cc:33-36: logf and a double log, as glibc computes them)
+ * and the initial merge priority (segment.cc:107-150), laid out [offset][source pixel] with NaN where
+ * the edge leaves the image; d_cls_out [H*W] uint8 arg-max class (may be NULL).  Synchronises. */
+int mn_exact_phase_a_device(mn_context* ctx, const float* d_class_pred, int class_dim,
+                            const float* d_adj_pred, int offset_dim, int img_width, int img_height,
+                            int num_classes, const int* offset_list, const mn_options* opts, void* stream,
+                            unsigned char* d_cls_out, float* d_oml_out, float* d_prio_out);
 
 /* Host-pointer convenience: copies in, runs mn_segment_device, copies out. */
 int mn_segment_host(mn_context* ctx, const float* class_pred, int class_dim, const float* adj_pred,

@@ -855,7 +855,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
 // The loop kernel is ONE wavefront that runs until the queue is empty; it comes back early when its
 // step budget is used up (MN_X_BUDGET: block maxima are rebuilt and it is launched again) or when the
 // adjacency arena is full.  `ev[1]`, `ev[2]` bracket the two set-up kernels (class terms / records).
-static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
+static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   int rc = x_ensure(c, P.N, P.O, P.C);
   if (rc != MN_OK) return rc;
   mn_context::XWork& w = c->xw;
@@ -872,6 +872,16 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   hipLaunchKernelGGL(mn_x_init_records, dim3(grid_for((size_t)X.NL, 256)), dim3(256), 0, st, P, X);
   hipLaunchKernelGGL(mn_x_place_overflow, dim3(1), dim3(64), 0, st, X);
   MN_HIP(hipEventRecord(c->ev[2], st));
+  MN_HIP(hipGetLastError());
+  return MN_OK;
+}
+
+static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
+  int rc = exact_setup(c, P, st);
+  if (rc != MN_OK) return rc;
+  mn_context::XWork& w = c->xw;
+  XState& X = w.X;
+  const size_t N = (size_t)P.N;
   const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + 64;
   if (!w.lds_ready) {
     MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
@@ -1051,9 +1061,9 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
         (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;
-  // the sequential order at any size: the exact engine (C++ variant; the Python variant's float64
-  // state stays with the small-list finisher; debug_flags bit 8 keeps the old engine for comparison)
-  const bool xengine = mode == MN_MODE_EXACT && opts->variant == MN_VARIANT_CSEGMENT && !(opts->debug_flags & 256);
+  // the sequential order at any size: the exact engine (debug_flags bit 8 keeps the small-list finisher
+  // with its O(R) arg-max per step, for comparison)
+  const bool xengine = mode == MN_MODE_EXACT && !(opts->debug_flags & 256);
   ObjState S = obj_state(c);
   // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
   // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph
@@ -1178,7 +1188,11 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     const double tau = fmax(2.0 * n * ulp, 1e-30 * n * n) / (double)P.omf;
     tau_fixed = (i64)ceil(tau * MN_FIX_ONE) + 1;
   }
-  const bool clusters = mode == MN_MODE_ROUNDS && cores_ok && !(opts->debug_flags & 8);
+  // Contraction of order-free clusters of OBJECTS is opt-in (debug_flags bit 9): its argument assumes
+  // every record fresh, while the reference keeps a survivor's records at the priority of their last
+  // re-score (segment.cc:650-707) -- re-scoring the records of a contracted cluster changes the pop order
+  // of the second phase (the crowded seed 6408 lost its equality with the reference that way in round 2).
+  const bool clusters = mode == MN_MODE_ROUNDS && cores_ok && (opts->debug_flags & 512) && !(opts->debug_flags & 8);
   if (clusters && R > 0) {
     // order-free clusters of the initial objects (on a sign-separable map: everything)
     bool merged = false;
@@ -1506,6 +1520,11 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
   if (!c || !c->pend.active) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
   mn_context::Pending& q = c->pend;
   int rc;
+  // require_proof: 1 = always, -1 = never, 0 = by mode -- AUTO hands back proven results only, an
+  // explicitly requested ROUNDS / COMPONENTS run is taken as a request for that engine's answer
+  const bool explicit_mode = q.opts.mode == MN_MODE_EXACT || q.opts.mode == MN_MODE_ROUNDS ||
+                             q.opts.mode == MN_MODE_COMPONENTS;
+  const bool must_prove = q.opts.require_proof > 0 || (q.opts.require_proof == 0 && !explicit_mode);
   if (q.active == 2) {
     rc = q.rc;
   } else {
@@ -1514,21 +1533,25 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
     memset(&q.stats, 0, sizeof(q.stats));
     rc = segment_read_back(c, &q.opts, q.mode, true, q.finish_limit, q.N, q.R0, q.rounds, q.want_cert,
                            &q.stats);
-    if (rc == MN_RETRY_ROUNDS || rc == MN_RETRY_WAIT)
+    // a speculative attempt that does not hold is redone: by the sequential order itself when the
+    // caller wants a proven result and the input is not sign-separable (the rounds would only
+    // approximate it), else on the ordinary path
+    if (rc == MN_RETRY_ROUNDS && must_prove)
+      rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
+                           q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
+                           MN_MODE_EXACT, false);
+    else if (rc == MN_RETRY_ROUNDS || rc == MN_RETRY_WAIT)
       rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
                            q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
                            rc == MN_RETRY_ROUNDS ? MN_MODE_ROUNDS : 0, false);
   }
-  // require_proof: a result that is only an approximation of the reference's order is redone in
-  // the sequential order when that is affordable, otherwise the caller is told
-  if (rc == MN_OK && q.opts.require_proof && q.stats.proof == 0) {
-    const long long lim = q.opts.exact_limit > 0 ? q.opts.exact_limit : 32768;
-    if (q.stats.initial_records <= 8 * lim)
-      rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
-                           q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
-                           MN_MODE_EXACT, false);
-    else
-      rc = MN_ERR_UNPROVEN;
+  // A result that is neither certified nor from the sequential order is only an approximation of the
+  // reference's result on an order-dependent input: redone by the exact engine (any image size).
+  if (rc == MN_OK && must_prove && q.stats.proof == 0) {
+    rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
+                         q.offs, q.d_mask, q.d_objcls, q.d_part, &q.opts, q.stream, &q.stats,
+                         MN_MODE_EXACT, false);
+    if (rc == MN_ERR_CAPACITY) rc = MN_ERR_UNPROVEN;      // (no room for the engine's workspace)
     if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
   }
   if (stats) *stats = q.stats;
@@ -1579,6 +1602,32 @@ extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int cla
   if (ms_class_pass) *ms_class_pass = ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
   if (ms_edge_pass) *ms_edge_pass = ms;
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+// Phase A of the exact engine (tests): log-odds and initial priority of every record in the layout
+// of the oracle's phase-A export ([offset][source pixel], NaN outside the image), arg-max classes.
+extern "C" int mn_exact_phase_a_device(mn_context* c, const float* d_class_pred, int class_dim,
+                                       const float* d_adj_pred, int offset_dim, int W, int H,
+                                       int num_classes, const int* offset_list, const mn_options* opts,
+                                       void* stream, unsigned char* d_cls_out, float* d_oml_out,
+                                       float* d_prio_out) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!d_class_pred || !d_adj_pred || !d_oml_out || !d_prio_out)) rc = MN_ERR_ARGUMENT;
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ImgParams P;
+  fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  rc = exact_setup(c, P, st);
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  hipLaunchKernelGGL(mn_x_export_phase_a, dim3(grid_for((size_t)P.N * P.O, 256)), dim3(256), 0, st, P, c->xw.X,
+                     d_oml_out, d_prio_out, d_cls_out);
+  MN_HIP(hipGetLastError());
+  MN_HIP(hipStreamSynchronize(st));
   g_last_status = MN_OK;
   return MN_OK;
 }
@@ -1649,7 +1698,8 @@ extern "C" void c_run_segmentation(float* class_pred, int class_dim, float* adj_
   o.same_different_bias = same_different_bias;
   o.object_merge_factor = object_merge_factor;
   o.merge_logprob_bias = merge_logprob_bias;
-  o.compute_logprob = 0;
+  // (AUTO with the certificate: the reference's own result -- a separable map is proven by the fast
+  //  path's certificate, anything else goes through the exact engine)
   const int rc = mn_segment_host(cached, class_pred, class_dim, adj_pred, offset_dim, img_width,
                                  img_height, num_classes, offset_list, output, object_class, NULL,
                                  &o, NULL);

@@ -37,6 +37,8 @@
 // negative edges, so the check -- not luck -- keeps this shortcut safe.
 #pragma once
 
+static_assert(MN_MAX_OFFSETS <= 32, "edge masks are 32-bit words: one bit per offset");
+
 #include "mn_device.h"
 #include "mn_kernels_merge.h"
 
@@ -213,7 +215,9 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
     if (fast) {
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const unsigned bit = 1u << ((k0 + g) & 31);
+        // (a group may run past the last offset: a phantom offset k >= 32 must not wrap onto bits 0..2,
+        //  where its neutral value 1.0 would forge positive edges -- MN_MAX_OFFSETS is 32)
+        const unsigned bit = (k0 + g < P.O) ? (1u << ((k0 + g) & 31)) : 0u;
 #pragma unroll
         for (int j = 0; j < PX; j++) {
           const float x = (PLAIN || first[g] != INT_MIN) ? mn_cc_value<PLAIN>(P, v[g][j]) : 1.0f;
@@ -225,7 +229,9 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
     } else {
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const unsigned bit = 1u << ((k0 + g) & 31);
+        // (a group may run past the last offset: a phantom offset k >= 32 must not wrap onto bits 0..2,
+        //  where its neutral value 1.0 would forge positive edges -- MN_MAX_OFFSETS is 32)
+        const unsigned bit = (k0 + g < P.O) ? (1u << ((k0 + g) & 31)) : 0u;
 #pragma unroll
         for (int j = 0; j < PX; j++) {
           // first[g] == INT_MIN (row outside / no such offset) fails the column test

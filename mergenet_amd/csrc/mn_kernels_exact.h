@@ -93,40 +93,7 @@ struct XState {
   XCtl* ctl;
 };
 
-// ---- glibc's logf, bit for bit -------------------------------------------------------------------
-// The reference calls log(float) = logf for the class and sameness terms (segment.h:296, segment.cc:
-// 35); its float32 decisions depend on the exact values.  glibc 2.35 (the image's libm, and the
-// published algorithm of sysdeps/ieee754/flt-32/e_logf.c) evaluates, in double precision,
-//   log x = log1p(z / c - 1) + log c + k ln 2,  16-entry table of (1/c, log c), cubic in r = z/c - 1.
-// Restated here with the operation order of the FMA variant x86-64 dispatches to; checked against
-// the host's logf on all 2.13e9 positive normal floats (tests/test_ref_logf.py runs a sample).
-// Inputs are clipped to [2^-23, 1 - 2^-23] (c_segment.pyx:53-55): no zero, subnormal, inf or NaN.
-__device__ __forceinline__ float mn_ref_logf(float x) {
-  const double T[16][2] = {
-      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
-      {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2}, {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
-      {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
-      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
-      {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1.0000000000000p+0, 0x0.0p+0},
-      {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
-      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
-      {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
-  const unsigned ix = __float_as_uint(x);
-  if (ix == 0x3f800000u) return 0.0f;
-  const unsigned tmp = ix - 0x3f330000u;
-  const int i = (int)((tmp >> 19) & 15u);
-  const int k = (int)tmp >> 23;
-  const unsigned iz = ix - (tmp & 0xff800000u);
-  const double z = (double)__uint_as_float(iz);
-  const double invc = T[i][0], logc = T[i][1];
-  const double y0 = fma((double)k, 0x1.62e42fefa39efp-1, logc);
-  const double r = fma(z, invc, -1.0);
-  double y = fma(r, 0x1.5575b0be00b6ap-2, -0x1.ffffef20a4123p-2);
-  const double r2 = r * r;
-  const double t = r + y0;
-  y = fma(r2, -0x1.00ea348b88334p-2, y);
-  return (float)fma(r2, y, t);
-}
+#include "mn_ref_logf.h"
 
 // differentness_logprob = log(1.0 - same_prob): a double log rounded to float (segment.cc:34)
 __device__ __forceinline__ float mn_ref_log1m(float v) { return (float)log(1.0 - (double)v); }
@@ -189,6 +156,14 @@ __device__ __forceinline__ u64 mn_x_wmax_pair(u64 v) {
   return ((u64)mh << 32) | (u64)ml;
 }
 
+// the quotient of the priority (segment.cc:147-149; the Python variant divides by n1 * n2 with the bias
+// inside, segmenter.py:190-193)
+__device__ __forceinline__ float mn_x_quotient(const ImgParams& P, float num, int n1, int n2) {
+  if (P.variant == MN_VARIANT_CSEGMENT)
+    return num / (float)((unsigned long long)n1 + (unsigned long long)n2) + P.bias;
+  return (num + P.bias) / ((float)n1 * (float)n2);
+}
+
 __device__ __forceinline__ u64 mn_hash64(u64 k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;
@@ -236,8 +211,7 @@ __device__ __forceinline__ float mn_x_score1(const ImgParams& P, const float* la
     cdl = (bestv - lca) - lcb;
   }
   *mc = m;
-  const float den = (float)((unsigned long long)na + (unsigned long long)nb);
-  return (S * P.omf + cdl) / den + P.bias;
+  return mn_x_quotient(P, S * P.omf + cdl, na, nb);
 }
 
 // Insertion by ONE lane with everything read afresh (the rare paths: a record the parallel set-up could
@@ -519,12 +493,13 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
                                 : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay1), cys - 64));
       cdl = (jm - lx) - ly;
     }
-    const float den = (float)((unsigned long long)nx + (unsigned long long)ny);
-    const float f = (S * P.omf + cdl) / den + P.bias;
+    const float f = mn_x_quotient(P, S * P.omf + cdl, nx, ny);
     const unsigned fw = mn_x_word(f);
     steps++;
     MN_X_STAMP(3);
-    if (fw != gword) {
+    // merge when the fresh value is what the queue promised (segment.cc:561; the Python variant
+    // merges on >=, segmenter.py:470)
+    if (P.variant == MN_VARIANT_CSEGMENT ? (fw != gword) : (fw < gword)) {
       // ---- not what the queue promised: store the fresh value (segment.cc:563-565) ----
       if (lane == 0) {
         X.leaf[rid] = fw;
@@ -721,8 +696,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
           }
           cdl3 = (a < c3) ? ((bestv - la_c) - l3_c) : ((bestv - l3_c) - la_c);
         }
-        const float den3 = (float)((unsigned long long)na + (unsigned long long)n3);
-        w = mn_x_word((Sn * P.omf + cdl3) / den3 + P.bias);
+        w = mn_x_word(mn_x_quotient(P, Sn * P.omf + cdl3, na, n3));
         X.leaf[tr] = w;
       }
       // ---- queue: a raised or new value goes into the block and group maxima by LDS atomics; a block
@@ -792,6 +766,28 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     c->folded += folded; c->adopted += adopted; c->slow_inserts += slow_inserts;
     c->bump = bump;
   }
+}
+
+// Phase A as the engine holds it, in the layout of the oracle's phase-A export (tests): per (offset, source
+// pixel) the record's log-odds and initial priority, NaN where the edge leaves the image.
+__global__ __launch_bounds__(256) void mn_x_export_phase_a(ImgParams P, XState X, float* __restrict__ oml_out,
+                                                           float* __restrict__ prio_out,
+                                                           unsigned char* __restrict__ cls_out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)P.N * P.O) return;
+  const int p = (int)(gid / P.O), k = (int)(gid - (size_t)p * P.O);
+  if (k == 0 && cls_out) cls_out[p] = (unsigned char)X.obj[p].cls;
+  const XRec R = X.rec[gid];
+  const size_t e = (size_t)k * P.N + p;
+  if (R.key == MN_EMPTY) {
+    oml_out[e] = __int_as_float(0x7FC00000);
+    prio_out[e] = __int_as_float(0x7FC00000);
+    return;
+  }
+  const int a = mn_key_u(R.key), b = mn_key_v(R.key);
+  int mc;
+  oml_out[e] = R.S;
+  prio_out[e] = mn_x_score1(P, X.lp + (size_t)a * P.C, X.lp + (size_t)b * P.C, X.obj[a].cls, X.obj[b].cls, 1, 1, R.S, &mc);
 }
 
 // ---- hand-over to the output stage -------------------------------------------------------------------

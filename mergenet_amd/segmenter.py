@@ -33,6 +33,9 @@ MN_ERR_NO_BACKGROUND = -10
 MN_ERR_UNPROVEN = -30
 MN_DEBUG_GENERIC_EDGE_PASS, MN_DEBUG_NO_EVENTS, MN_DEBUG_NO_CORES, MN_DEBUG_NO_CLUSTERS = 1, 2, 4, 8
 MN_DEBUG_LEAN_EVENTS, MN_DEBUG_REPLAY = 16, 32
+MN_DEBUG_CLUSTERS = 512           # general rounds: contract order-free clusters of objects (opt-in)
+MN_DEBUG_OLD_EXACT = 256          # MN_MODE_EXACT by the small-list finisher instead of the exact engine
+MN_PROVE_ALWAYS, MN_PROVE_BY_MODE, MN_PROVE_NEVER = 1, 0, -1   # mn_options.require_proof
 MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
 
 SegmenterOptions = namedtuple("SegmenterOptions",
@@ -74,7 +77,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
-           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_segment_host", "c_run_segmentation",
+           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_exact_phase_a_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
            "mn_last_status", "mn_status_string", "mn_version"]
@@ -119,6 +122,11 @@ def load_library() -> ctypes.CDLL:
                                     ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, _f32p, _f32p]
     lib.mn_score_device.restype = ctypes.c_int
+    lib.mn_exact_phase_a_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
+                                            ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+    lib.mn_exact_phase_a_device.restype = ctypes.c_int
     lib.mn_segment_host.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p,
                                     _i32p, ctypes.POINTER(MnOptions), ctypes.POINTER(MnStats)]
@@ -465,6 +473,25 @@ class Merger:
             return a.value, b.value, cls, best
         return a.value, b.value
 
+
+    def exact_phase_a(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None):
+        """Phase A of the exact engine: (cls uint8[H,W], oml float32[O,H,W], prio float32[O,H,W]) in the
+        layout of the oracle's phase-A export (NaN where an edge leaves the image)."""
+        torch = self.torch
+        C, H, W, O, off = self._check(class_probs, same_probs, offsets)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs.device
+        cls = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        oml = torch.empty((O, H, W), dtype=torch.float32, device=dev)
+        prio = torch.empty((O, H, W), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_exact_phase_a_device(self.handle, class_probs.data_ptr(), C, same_probs.data_ptr(),
+                                              O, W, H, C, off.ctypes.data_as(_i32p), ctypes.byref(opts),
+                                              ctypes.c_void_p(stream), cls.data_ptr(), oml.data_ptr(),
+                                              prio.data_ptr())
+        if rc != 0:
+            raise MergeNetError(rc)
+        return cls, oml, prio
 
     def prepare(self, maps, out_height: int, out_width: int, apply_sigmoid: bool = False,
                 clip: bool = True):
