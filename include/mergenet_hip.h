@@ -214,6 +214,23 @@ int mn_score_device(mn_context* ctx, const float* d_class_pred, int class_dim,
                     unsigned char* d_cls_out, unsigned long long* d_best_out, float* ms_class_pass,
                     float* ms_edge_pass);
 
+/* The affinity-scoring sweep of the default path alone (mn_cc_sign: ONE read of the C class planes and the
+ * O sameness planes) and what it leaves behind, for the parity test of the sweep itself against the
+ * oracle's phase A (segment.cc:5-46):
+ *   d_bits_out [H*W] uint32   bit k = out-edge of offset k is in bounds and positive (value >= sep_hi)
+ *   d_neg_out  [O][H*W] f32   log-odds of every NEGATIVE in-bounds edge the sweep listed, NaN elsewhere
+ *   d_cls_out  [H*W] uint8    per-pixel arg-max class            (only written in the fused-class form)
+ *   d_gsum_out [C][H*W/4] i32 per lane and class the 2^-24 fixed-point log of the product of its four
+ *                             pixels' class values             (only written in the fused-class form)
+ *   logsum_out (host)         the certificate's sum over in-bounds edges of log max(v, 1 - v)
+ *   info_out   (host) int[3]  {pixels per lane (4 | 1), fused-class form (1 | 0), edges inside the
+ *                             float32 rounding margin of 0.5 (they fail the separability check)}
+ * d_cls_out / d_gsum_out may be NULL.  Synchronises. */
+int mn_sweep_device(mn_context* ctx, const float* d_class_pred, int class_dim, const float* d_adj_pred,
+                    int offset_dim, int img_width, int img_height, int num_classes, const int* offset_list,
+                    const mn_options* opts, void* stream, unsigned* d_bits_out, float* d_neg_out,
+                    unsigned char* d_cls_out, int* d_gsum_out, double* logsum_out, int* info_out);
+
 /* Phase A of the exact engine alone (tests pin it against the oracle, bit for bit): per record the
  * float32 log-odds obj_merge_logprob (segment.cc:33-36: logf and a double log, as glibc computes them)
  * and the initial merge priority (segment.cc:107-150), laid out [offset][source pixel] with NaN where

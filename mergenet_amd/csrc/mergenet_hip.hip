@@ -655,12 +655,12 @@ static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, 
 template <int PX>
 static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
                          u64* neg_list, unsigned sub_cap, bool cls = false, const unsigned* hook_bits = nullptr,
-                         hipEvent_t hook_done = nullptr) {
+                         hipEvent_t hook_done = nullptr, bool lean_cls = false) {
   const int N = P.N, ngroups = (N + PX - 1) / PX;
   if (!hook) {
     const dim3 g(grid_for(ngroups, MN_CC_SIGN_THREADS)), b(MN_CC_SIGN_THREADS);
     ClsOut CO;
-    CO.ocls = c->ocls; CO.cls0 = c->cls0; CO.lpvalid = c->lpvalid;
+    CO.ocls = lean_cls ? nullptr : c->ocls; CO.cls0 = c->cls0; CO.lpvalid = lean_cls ? nullptr : c->lpvalid;
     CO.gsum = reinterpret_cast<int*>(c->lpsum);     // (the summed class log-probs are written later, at roots only)
     CO.gstride = (size_t)P.N;
     const bool plain = !P.clip && P.sdb == 0.0f;
@@ -723,7 +723,9 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // caller's stream costs a ~6 us dispatch gap)
   // the sweep takes the class planes too when a lane's four pixels are four pixels of the image
   const bool fused_cls = four && (N & 3) == 0;
-  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls);
+  // (pure components mode: the roots' class and validity flag are set by mn_cc_finish)
+  const bool lean_cls = fused_cls && !cores;
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls, nullptr, nullptr, lean_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
   if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
@@ -752,9 +754,31 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     MN_HIP(hipStreamBeginCapture(c->replay.cap, hipStreamCaptureModeThreadLocal));
     st = c->replay.cap;
   }
+  unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
+  const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing;
+  bool fork_by_hook = false;
+  if (c->debug_flags & 1024) {
+    // (opt-in, slower so far: 8.7 + 25 + 9 + 30 us against 59 us) labelling by row runs in 16 x 256 tiles (mn_cc_tiles2 / mn_cc_link / mn_cc_flat_roots)
+    const unsigned lanes = (unsigned)(((P.W + 3) >> 2) * P.H);
+    const dim3 tiles2((P.W + MN_T2_COLS - 1) / MN_T2_COLS, (P.H + MN_T2_ROWS - 1) / MN_T2_ROWS);
+    hipLaunchKernelGGL(mn_cc_tiles2, tiles2, dim3(MN_T2_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv);
+    if (kh >= 0 || kv >= 0) hipLaunchKernelGGL(mn_cc_borders2, tiles2, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv);
+    if (kh >= 0) kmask &= ~(1u << kh);
+    if (kv >= 0) kmask &= ~(1u << kv);
+    const dim3 gf(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256));
+    hipLaunchKernelGGL(mn_cc_flat_roots, gf, b, 0, st, P, c->parent, c->osize, c->lp_acc, clsmin, clsmax, c->matched);
+    // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
+    fork_by_hook = fork_ext && kmask;
+    if (kmask) {
+      const dim3 gl(8 * ((grid_for(lanes, 256) + 7) / 8));
+      if (fork_by_hook)
+        hipExtLaunchKernelGGL(mn_cc_link, gl, b, 0, st, nullptr, c->ev_fork, 0, P, lbits, c->parent, kh, kv, dv, kmask);
+      else
+        hipLaunchKernelGGL(mn_cc_link, gl, b, 0, st, P, lbits, c->parent, kh, kv, dv, kmask);
+    }
+  } else {
   hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(MN_CC_TILE_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv,
                      c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
-  unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
   if (kh >= 0 || kv >= 0) {
     hipLaunchKernelGGL(mn_cc_borders, tiles, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv);
     if (kh >= 0) kmask &= ~(1u << kh);
@@ -762,10 +786,11 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
   // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
-  const bool fork_by_hook = fork_before_sums && kmask && c->ext_events && !c->replay.capturing;
+  fork_by_hook = fork_ext && kmask;
   if (kmask) {
     if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
     else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
+  }
   }
   if (c->replay.capturing) {
     MN_HIP(hipStreamEndCapture(c->replay.cap, &c->replay.gA));
@@ -823,7 +848,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   hipLaunchKernelGGL(mn_cc_finish, dim3(grid_for((size_t)(N >> 4) > 0 ? (size_t)(N >> 4) : 1, 256)), b, 0, st, P, S,
                      (const unsigned char*)c->matched, (const i64*)c->lp_acc,
                      (const int*)clsmin, (const int*)clsmax, c->mate, cores ? (int*)nullptr : c->cc_roots,
-                     c->scalars + 8, c->scalars + 6);  // `mate` is free in this mode: it keeps the component sizes
+                     c->scalars + 8, c->scalars + 6, lean_cls ? (const unsigned char*)c->cls0 : (const unsigned char*)nullptr);  // `mate` is free in this mode: it keeps the component sizes
   if (cores) {
     const unsigned all = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
     if (kshort != all) {           // a core with a non-positive edge inside falls apart again
@@ -1466,7 +1491,7 @@ extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int c
     const bool timed = !(q.opts.debug_flags & 2) && !c->ext_events;
     if (timed) MN_HIP(hipEventRecord(c->ev[0], st));
     launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist,
-                    (unsigned)((size_t)MN_CC_SIGN_THREADS * 4 * (size_t)P.O), true);
+                    (unsigned)((size_t)MN_CC_SIGN_THREADS * 4 * (size_t)P.O), true, nullptr, nullptr, true);
     if (timed) MN_HIP(hipEventRecord(c->ev[10], st));
     MN_HIP(hipGraphLaunch(rp.eA, st));
     MN_HIP(hipEventRecord(c->ev_fork, st));
@@ -1602,6 +1627,56 @@ extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int cla
   if (ms_class_pass) *ms_class_pass = ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
   if (ms_edge_pass) *ms_edge_pass = ms;
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+// The affinity-scoring sweep of the default path alone (mn_cc_sign), and what it leaves, for the parity
+// test against the oracle's phase A (see include/mergenet_hip.h).
+extern "C" int mn_sweep_device(mn_context* c, const float* d_class_pred, int class_dim,
+                               const float* d_adj_pred, int offset_dim, int W, int H, int num_classes,
+                               const int* offset_list, const mn_options* opts, void* stream,
+                               unsigned* d_bits_out, float* d_neg_out, unsigned char* d_cls_out,
+                               int* d_gsum_out, double* logsum_out, int* info_out) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!d_class_pred || !d_adj_pred || !d_bits_out || !d_neg_out)) rc = MN_ERR_ARGUMENT;
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ImgParams P;
+  fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
+  const int N = P.N;
+  c->debug_flags = opts->debug_flags | 2;          // (no events)
+  c->ext_events = 0;
+  c->cc_clean = 0;
+  const bool four = P.W % 4 == 0;
+  const bool fused_cls = four && (N & 3) == 0;
+  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);
+  MN_HIP(hipMemsetAsync(c->scalars, 0, MN_NSCALARS * sizeof(int), st));
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist, neg_cap, fused_cls);
+  else launch_cc_px<1>(c, P, st, 0u, false, c->cc_neglist, neg_cap);
+  MN_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_neg_out), 0x7FC00000, (size_t)P.O * N, st));
+  hipLaunchKernelGGL(mn_cc_export_neg, dim3((unsigned)sign_blocks), dim3(256), 0, st, N, (const u64*)c->cc_neglist,
+                     neg_cap, (const unsigned*)c->cc_negcnt, d_neg_out);
+  MN_HIP(hipMemcpyAsync(d_bits_out, c->cc_bits, (size_t)N * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+  if (d_cls_out && fused_cls) MN_HIP(hipMemcpyAsync(d_cls_out, c->cls0, (size_t)N, hipMemcpyDeviceToDevice, st));
+  if (d_gsum_out && fused_cls)          // (plane c of the sweep's products starts at c * N ints and holds N / 4 of them)
+    MN_HIP(hipMemcpy2DAsync(d_gsum_out, (size_t)(N / 4) * sizeof(int), c->lpsum, (size_t)N * sizeof(int),
+                            (size_t)(N / 4) * sizeof(int), (size_t)P.C, hipMemcpyDeviceToDevice, st));
+  double* hp = static_cast<double*>(malloc(sign_blocks * 2 * sizeof(double)));
+  if (!hp) return MN_ERR_INTERNAL;
+  MN_HIP(hipMemcpyAsync(hp, c->partial, sign_blocks * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, MN_NSCALARS * sizeof(int), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipStreamSynchronize(st));
+  double t = 0.0;
+  for (size_t b = 0; b < sign_blocks; b++) t += hp[2 * b];
+  free(hp);
+  if (logsum_out) *logsum_out = t;
+  if (info_out) { info_out[0] = four ? 4 : 1; info_out[1] = fused_cls ? 1 : 0; info_out[2] = c->h_scalars[6]; }
+  MN_HIP(hipGetLastError());
   g_last_status = MN_OK;
   return MN_OK;
 }

@@ -154,9 +154,11 @@ __device__ __forceinline__ void mn_cc_class_part(const ImgParams& P, const ClsOu
   if (prev.w >= best.w * near) b3 = mn_cc_argmax_logf(P, 4 * i + 3);
   uchar4 o;
   o.x = (unsigned char)b0; o.y = (unsigned char)b1; o.z = (unsigned char)b2; o.w = (unsigned char)b3;
-  *reinterpret_cast<uchar4*>(CO.ocls + 4 * (size_t)i) = o;
+  // (pure components mode: only the component roots' class and validity flag are ever read, and
+  //  mn_cc_finish sets those: two byte planes fewer to write -- ocls / lpvalid null)
+  if (CO.ocls) *reinterpret_cast<uchar4*>(CO.ocls + 4 * (size_t)i) = o;
   *reinterpret_cast<uchar4*>(CO.cls0 + 4 * (size_t)i) = o;
-  *reinterpret_cast<uchar4*>(CO.lpvalid + 4 * (size_t)i) = make_uchar4(0, 0, 0, 0);
+  if (CO.lpvalid) *reinterpret_cast<uchar4*>(CO.lpvalid + 4 * (size_t)i) = make_uchar4(0, 0, 0, 0);
 }
 
 template <int PX, bool PLAIN, bool CLS>
@@ -317,6 +319,21 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
                          (u64)__float_as_uint(oml);
     }
     __syncthreads();
+  }
+}
+
+// What the sweep leaves, for the parity test of the sweep itself (mn_sweep_device): the negative-edge
+// list (one region per block) scattered into a dense [O][N] array of log-odds.
+__global__ __launch_bounds__(256) void mn_cc_export_neg(int N, const u64* __restrict__ neg_list, unsigned sub_cap,
+                                                        const unsigned* __restrict__ neg_count,
+                                                        float* __restrict__ out) {
+  const u64* mylist = neg_list + (size_t)blockIdx.x * sub_cap;
+  const unsigned n = min(neg_count[blockIdx.x], sub_cap);
+  for (unsigned t = threadIdx.x; t < n; t += 256) {
+    const u64 e = mylist[t];
+    const unsigned hi = (unsigned)(e >> 32);
+    const unsigned k = hi >> MN_CC_EDGE_PIXBITS, p = hi & ((1u << MN_CC_EDGE_PIXBITS) - 1u);
+    out[(size_t)k * N + p] = __uint_as_float((unsigned)e);
   }
 }
 
@@ -544,6 +561,270 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
         mn_cc_wave_union(parent, want, a, bb);
       }
     }
+  }
+}
+
+// ---- labelling by ROW RUNS in wide tiles (round 3) ------------------------------------------------------
+// The tile pipeline above spends 59 us per 1024x2048 image in four dependent launches (LDS union-find
+// per 16 x 64 tile over single pixels, border unions, a flatten, the sweep over the other offsets) and
+// moves 11x the bytes of the masks it reads.  Inside an instance nearly every horizontal unit edge is
+// positive, so a row falls into a few long RUNS; with runs as the union-find elements almost no pixel
+// ever enters it:
+//   mn_cc_tiles2      a block owns 16 rows x 256 columns: a wave takes a row (4 pixels per lane), run
+//                     starts from one ballot and one cross-lane read, vertical unit edges inside the tile
+//                     united in LDS -- a request that repeats the previous pixel's (same two runs) is
+//                     dropped, so two runs cost one union however long they are; parent[p] = tile root;
+//   mn_cc_borders2    the unit edges across tile borders (272 per tile, repeats dropped the same way);
+//   mn_cc_flat_roots  parent[p] = root, root candidates flagged, the roots' accumulators cleared;
+//   mn_cc_link        the other offsets: a lane compares the parents of its 4 pixels with those of the 4
+//                     neighbours (one unaligned 16-byte read per offset) -- equal for nearly every edge
+//                     now that the 4-connected regions are flat -- and again drops repeats.
+// (Measured on the way: runs across the whole image without the LDS stage -- the vertical unions then
+//  build chains as deep as the image is high, link sweep 100 us; tiles2 + one link sweep over ALL offsets
+//  without the flatten in between -- parents of different tiles never compare equal, 66 us.)
+#define MN_T2_ROWS 16
+#define MN_T2_COLS 256
+struct __attribute__((packed, aligned(4))) mn_uint4u { unsigned x, y, z, w; };
+
+__device__ __forceinline__ int mn_dpp_prev_lane(int v) {          // lane l gets lane l-1's value, lane 0 gets 0
+  return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);   // wave_shr:1
+}
+
+// lock-free union of the sets of x and y: the larger root is hooked under the smaller
+__device__ __forceinline__ void mn_cc_unite(int* __restrict__ parent, int x, int y) {
+  int a = mn_cc_find(parent, x), b = mn_cc_find(parent, y);
+  while (a != b) {
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&parent[a], b);
+    if (old == a) break;
+    a = mn_cc_find(parent, old);
+    b = mn_cc_find(parent, b);
+  }
+}
+
+__global__ __launch_bounds__(MN_T2_ROWS * 64) void mn_cc_tiles2(ImgParams P, const unsigned* __restrict__ bits,
+                                                               int* __restrict__ parent, int kh, int kv, int dv) {
+  __shared__ int lab[MN_T2_ROWS * MN_T2_COLS];
+  const int t = threadIdx.x, lane = t & 63, i = t >> 6;             // wave i = row i of the tile
+  const int r = (int)blockIdx.y * MN_T2_ROWS + i, c0 = (int)blockIdx.x * MN_T2_COLS + lane * 4;
+  const int nv = (r < P.H) ? max(0, min(4, P.W - c0)) : 0;
+  const int p0 = r * P.W + c0;
+  unsigned b[4] = {0u, 0u, 0u, 0u};
+  if (nv == 4) {
+    const mn_uint4u v = *reinterpret_cast<const mn_uint4u*>(bits + p0);
+    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+  } else {
+    for (int j = 0; j < nv; j++) b[j] = bits[p0 + j];
+  }
+  // link j: pixel j -> pixel j + 1 of the row (a set bit implies an in-bounds neighbour); the last
+  // lane's link leaves the tile (mn_cc_link takes it)
+  const bool l0 = kh >= 0 && ((b[0] >> kh) & 1u), l1 = kh >= 0 && ((b[1] >> kh) & 1u);
+  const bool l2 = kh >= 0 && ((b[2] >> kh) & 1u), l3 = kh >= 0 && ((b[3] >> kh) & 1u) && lane < 63;
+  const bool enter = mn_dpp_prev_lane(l3 ? 1 : 0) != 0;             // from the previous lane's last pixel
+  const int tail = !l2 ? 3 : (!l1 ? 2 : (!l0 ? 1 : 0));             // first pixel of the run that leaves the lane
+  const bool transparent = enter && l0 && l1 && l2;                 // one run passes through
+  const u64 nt = __ballot(!transparent);
+  const u64 below = nt & ((1ull << lane) - 1ull);
+  const int src = below ? (63 - __clzll((long long)below)) : 0;     // nearest lane below where the entering run starts
+  const int base = i * MN_T2_COLS + lane * 4;                       // local id of the lane's first pixel
+  const int sin = __shfl(base + tail, src);
+  int s[4];
+  s[0] = enter ? sin : base;
+  s[1] = l0 ? s[0] : base + 1;
+  s[2] = l1 ? s[1] : base + 2;
+  s[3] = l2 ? s[2] : base + 3;
+  *reinterpret_cast<int4*>(&lab[base]) = make_int4(s[0], s[1], s[2], s[3]);
+  __syncthreads();
+  // vertical unit edges that stay inside the tile
+  const int ni = i + dv;
+  if (kv >= 0 && ni >= 0 && ni < MN_T2_ROWS) {
+    const int4 nb = *reinterpret_cast<const int4*>(&lab[ni * MN_T2_COLS + lane * 4]);
+    const int q[4] = {nb.x, nb.y, nb.z, nb.w};
+    bool req[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> kv) & 1u) != 0u;
+    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
+    const int ps = mn_dpp_prev_lane(s[3]), pq = mn_dpp_prev_lane(q[3]);
+    bool go[4];
+    go[0] = req[0] && !(preq && ps == s[0] && pq == q[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && s[j - 1] == s[j] && q[j - 1] == q[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (go[j]) mn_cc_unite(lab, s[j], q[j]);
+  }
+  __syncthreads();
+  if (nv == 0) return;
+  int o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int x = (j > 0 && s[j] == s[j - 1]) ? -1 : s[j];
+    if (x >= 0) { while (lab[x] != x) x = lab[x]; }
+    o[j] = x >= 0 ? ((int)blockIdx.y * MN_T2_ROWS + (x >> 8)) * P.W + (int)blockIdx.x * MN_T2_COLS + (x & (MN_T2_COLS - 1))
+                  : o[j > 0 ? j - 1 : 0];
+  }
+  if (nv == 4) {
+    mn_int4u w; w.x = o[0]; w.y = o[1]; w.z = o[2]; w.w = o[3];
+    *reinterpret_cast<mn_int4u*>(parent + p0) = w;
+  } else {
+    for (int j = 0; j < nv; j++) parent[p0 + j] = o[j];
+  }
+}
+
+// unit edges across the borders of the 16 x 256 tiles: wave 0 takes the 256 vertical edges that leave the
+// tile (4 per lane), wave 1 the 16 horizontal ones across its right border; repeats of the previous
+// pixel's request are dropped, so a border segment inside one pair of components costs one union
+__global__ __launch_bounds__(128) void mn_cc_borders2(ImgParams P, const unsigned* __restrict__ bits,
+                                                      int* __restrict__ parent, int kh, int kv, int dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (int)blockIdx.y * MN_T2_ROWS, cb = (int)blockIdx.x * MN_T2_COLS;
+  if (wave == 0) {
+    if (kv < 0) return;
+    const int r = dv > 0 ? min(r0 + MN_T2_ROWS - 1, P.H - 1) : r0;
+    // (a tile cut by the image's lower edge has no lower border; its rows' bits are clear there anyway)
+    if (dv > 0 && r0 + MN_T2_ROWS - 1 >= P.H) return;
+    if (r + dv < 0 || r + dv >= P.H) return;
+    const int c0 = cb + lane * 4;
+    const int nv = max(0, min(4, P.W - c0));
+    const int p0 = r * P.W + c0, q0 = p0 + dv * P.W;
+    unsigned b[4] = {0u, 0u, 0u, 0u};
+    int own[4] = {-1, -2, -3, -4}, rq[4] = {-1, -2, -3, -4};
+    if (nv == 4) {
+      const mn_uint4u t = *reinterpret_cast<const mn_uint4u*>(bits + p0);
+      b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+      const int4 o = mn_ld_int4_unaligned(parent + p0), n = mn_ld_int4_unaligned(parent + q0);
+      own[0] = o.x; own[1] = o.y; own[2] = o.z; own[3] = o.w;
+      rq[0] = n.x; rq[1] = n.y; rq[2] = n.z; rq[3] = n.w;
+    } else {
+      for (int j = 0; j < nv; j++) { b[j] = bits[p0 + j]; own[j] = parent[p0 + j]; rq[j] = parent[q0 + j]; }
+    }
+    bool req[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> kv) & 1u) && rq[j] != own[j];
+    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
+    const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[3]);
+    bool go[4];
+    go[0] = req[0] && !(preq && pown == own[0] && prq == rq[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[j - 1] == rq[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (go[j]) mn_cc_unite(parent, own[j], rq[j]);
+  } else {
+    if (kh < 0) return;
+    const int r = r0 + lane, c = cb + MN_T2_COLS - 1;
+    const bool in = lane < MN_T2_ROWS && r < P.H && c + 1 < P.W;
+    const int p = in ? r * P.W + c : 0;
+    int own = -1, rq = -2;
+    bool req = false;
+    if (in && ((bits[p] >> kh) & 1u)) { own = parent[p]; rq = parent[p + 1]; req = own != rq; }
+    const bool preq = mn_dpp_prev_lane(req ? 1 : 0) != 0;
+    const int pown = mn_dpp_prev_lane(own), prq = mn_dpp_prev_lane(rq);
+    if (req && !(preq && pown == own && prq == rq)) mn_cc_unite(parent, own, rq);
+  }
+}
+
+__global__ __launch_bounds__(256) void mn_cc_link(ImgParams P, const unsigned* __restrict__ bits,
+                                                  int* __restrict__ parent, int kh, int kv, int dv, unsigned kmask) {
+  const int lpr = (P.W + 3) >> 2, total = lpr * P.H;
+  const int tile = mn_xcd_tile((total + 255) >> 8, P.banded);
+  const int i = tile < 0 ? total : tile * 256 + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = i < total;
+  const int r = live ? i / lpr : 0, c0 = live ? ((i - r * lpr) << 2) : 0;
+  const int nv = live ? min(4, P.W - c0) : 0;
+  const int p0 = r * P.W + c0;
+  unsigned b[4] = {0u, 0u, 0u, 0u};
+  int own[4] = {-1, -2, -3, -4};
+  if (nv == 4) {
+    const mn_uint4u t = *reinterpret_cast<const mn_uint4u*>(bits + p0);
+    b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+    const int4 o = mn_ld_int4_unaligned(parent + p0);
+    own[0] = o.x; own[1] = o.y; own[2] = o.z; own[3] = o.w;
+  } else {
+    for (int j = 0; j < nv; j++) { b[j] = bits[p0 + j]; own[j] = parent[p0 + j]; }
+  }
+  // the unit offsets (if asked for at all) were taken by mn_cc_tiles2 except across tile borders
+  if (kh >= 0 && ((kmask >> kh) & 1u)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (((c0 + j) & (MN_T2_COLS - 1)) != MN_T2_COLS - 1) b[j] &= ~(1u << kh);
+  }
+  if (kv >= 0 && ((kmask >> kv) & 1u)) {
+    const bool border_row = dv > 0 ? ((r & (MN_T2_ROWS - 1)) == MN_T2_ROWS - 1) : ((r & (MN_T2_ROWS - 1)) == 0);
+    if (!border_row) { b[0] &= ~(1u << kv); b[1] &= ~(1u << kv); b[2] &= ~(1u << kv); b[3] &= ~(1u << kv); }
+  }
+  const unsigned any = (b[0] | b[1] | b[2] | b[3]) & kmask;
+  for (int k = 0; k < P.O; k++) {
+    if (!((kmask >> k) & 1u)) continue;
+    if (__ballot((any >> k) & 1u) == 0) continue;                   // uniform
+    const long long q0 = (long long)(r + P.di[k]) * P.W + c0 + P.dj[k];
+    int rq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rq[j] = own[j];
+    if ((any >> k) & 1u) {
+      if (q0 >= 0 && q0 + 3 < P.N) {
+        const int4 t = mn_ld_int4_unaligned(parent + q0);
+        rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (((b[j] >> k) & 1u) && q0 + j >= 0 && q0 + j < P.N) rq[j] = parent[q0 + j];
+      }
+    }
+    bool req[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> k) & 1u) && rq[j] != own[j];
+    // a request equal to the previous pixel's (same two sets asked for) is dropped
+    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
+    const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[3]);
+    bool go[4];
+    go[0] = req[0] && !(preq && lane != 0 && pown == own[0] && prq == rq[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[j - 1] == rq[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (go[j]) mn_cc_unite(parent, own[j], rq[j]);
+  }
+}
+
+// parent[p] = root for every pixel; the roots -- the component roots: no union follows -- are flagged
+// and their accumulators cleared (class sums, class range, size)
+__global__ __launch_bounds__(256) void mn_cc_flat_roots(ImgParams P, int* __restrict__ parent, int* __restrict__ osize,
+                                                        i64* __restrict__ lp_acc, int* __restrict__ clsmin,
+                                                        int* __restrict__ clsmax, unsigned char* __restrict__ cand) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = P.N, n4 = N >> 2;
+  auto root_of = [&](int x) { int y = parent[x]; while (y != x) { x = y; y = parent[x]; } return x; };
+  auto clear_root = [&](int p) {
+    osize[p] = 0;
+    for (int c = 0; c < P.C; c++) lp_acc[(size_t)c * N + p] = 0;
+    clsmin[p] = 255;
+    clsmax[p] = 0;
+  };
+  if (i < n4) {
+    const int p0 = 4 * i;
+    const int4 r = *reinterpret_cast<const int4*>(parent + p0);
+    int4 o;
+    o.x = (r.x == p0) ? p0 : root_of(r.x);
+    o.y = (r.y == r.x) ? o.x : ((r.y == p0 + 1) ? p0 + 1 : root_of(r.y));
+    o.z = (r.z == r.y) ? o.y : ((r.z == p0 + 2) ? p0 + 2 : root_of(r.z));
+    o.w = (r.w == r.z) ? o.z : ((r.w == p0 + 3) ? p0 + 3 : root_of(r.w));
+    if (o.x != r.x || o.y != r.y || o.z != r.z || o.w != r.w) *reinterpret_cast<int4*>(parent + p0) = o;
+    uchar4 cd;
+    cd.x = o.x == p0; cd.y = o.y == p0 + 1; cd.z = o.z == p0 + 2; cd.w = o.w == p0 + 3;
+    *reinterpret_cast<uchar4*>(cand + p0) = cd;
+    if (cd.x) clear_root(p0);
+    if (cd.y) clear_root(p0 + 1);
+    if (cd.z) clear_root(p0 + 2);
+    if (cd.w) clear_root(p0 + 3);
+  }
+  if (i < N - (n4 << 2)) {
+    const int p = (n4 << 2) + i;
+    const int x = root_of(p);
+    parent[p] = x;
+    cand[p] = x == p;
+    if (x == p) clear_root(p);
   }
 }
 
@@ -1173,8 +1454,13 @@ __device__ __forceinline__ void mn_cc_finish_root(const ImgParams& P, const ObjS
                                                   const int* __restrict__ clsmin,
                                                   const int* __restrict__ clsmax,
                                                   int* __restrict__ compsize, int* __restrict__ rootlist,
-                                                  int* __restrict__ nroots, int* __restrict__ violations) {
+                                                  int* __restrict__ nroots, int* __restrict__ violations,
+                                                  const unsigned char* __restrict__ cls0) {
   if (S.parent[p] != p) return;
+  if (cls0) {                              // (the sweep left the roots' class and validity flag to us)
+    S.ocls[p] = cls0[p];
+    S.lpvalid[p] = 0;
+  }
   if (rootlist) {                         // (null: cores ahead of the rounds -- no certificate from the contraction)
     rootlist[atomicAdd(nroots, 1)] = p;     // (component roots are few)
     compsize[p] = S.osize[p];               // kept for the certificate: osize grows in the merge
@@ -1194,7 +1480,8 @@ __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
                                                     int* __restrict__ compsize,
                                                     int* __restrict__ rootlist,
                                                     int* __restrict__ nroots,
-                                                    int* __restrict__ violations) {
+                                                    int* __restrict__ violations,
+                                                    const unsigned char* __restrict__ cls0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n16 = P.N >> 4;
   if (i < n16) {
@@ -1203,12 +1490,12 @@ __global__ __launch_bounds__(256) void mn_cc_finish(ImgParams P, ObjState S,
       const unsigned w[4] = {f.x, f.y, f.z, f.w};
       for (int j = 0; j < 16; j++)
         if ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu)
-          mn_cc_finish_root(P, S, 16 * i + j, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations);
+          mn_cc_finish_root(P, S, 16 * i + j, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations, cls0);
     }
   }
   if (i < P.N - (n16 << 4)) {
     const int p = (n16 << 4) + i;
-    if (cand[p]) mn_cc_finish_root(P, S, p, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations);
+    if (cand[p]) mn_cc_finish_root(P, S, p, lp_acc, clsmin, clsmax, compsize, rootlist, nroots, violations, cls0);
   }
 }
 

@@ -77,7 +77,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
-           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_exact_phase_a_device", "mn_segment_host", "c_run_segmentation",
+           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
            "mn_last_status", "mn_status_string", "mn_version"]
@@ -127,6 +127,11 @@ def load_library() -> ctypes.CDLL:
                                             ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]
     lib.mn_exact_phase_a_device.restype = ctypes.c_int
+    lib.mn_sweep_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, ctypes.POINTER(MnOptions),
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), _i32p]
+    lib.mn_sweep_device.restype = ctypes.c_int
     lib.mn_segment_host.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p,
                                     _i32p, ctypes.POINTER(MnOptions), ctypes.POINTER(MnStats)]
@@ -473,6 +478,31 @@ class Merger:
             return a.value, b.value, cls, best
         return a.value, b.value
 
+
+    def sweep(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None):
+        """The affinity-scoring sweep of the default path alone (mn_cc_sign).  Returns a dict: bits uint32[H,W]
+        (as int32 tensor), neg float32[O,H,W] (NaN = not listed), cls uint8[H,W] | None, gsum int32[C,H*W/4] |
+        None, logsum float, pixels_per_lane, fused_class, margin_edges."""
+        torch = self.torch
+        C, H, W, O, off = self._check(class_probs, same_probs, offsets)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs.device
+        bits = torch.empty((H, W), dtype=torch.int32, device=dev)
+        neg = torch.empty((O, H, W), dtype=torch.float32, device=dev)
+        cls = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+        gsum = torch.zeros((C, (H * W + 3) // 4), dtype=torch.int32, device=dev)
+        logsum = ctypes.c_double(0.0)
+        info = (ctypes.c_int * 3)()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_sweep_device(self.handle, class_probs.data_ptr(), C, same_probs.data_ptr(), O, W, H, C,
+                                      off.ctypes.data_as(_i32p), ctypes.byref(opts), ctypes.c_void_p(stream),
+                                      bits.data_ptr(), neg.data_ptr(), cls.data_ptr(), gsum.data_ptr(),
+                                      ctypes.byref(logsum), info)
+        if rc != 0:
+            raise MergeNetError(rc)
+        fused = bool(info[1])
+        return dict(bits=bits, neg=neg, cls=cls if fused else None, gsum=gsum if fused else None,
+                    logsum=logsum.value, pixels_per_lane=int(info[0]), fused_class=fused, margin_edges=int(info[2]))
 
     def exact_phase_a(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None):
         """Phase A of the exact engine: (cls uint8[H,W], oml float32[O,H,W], prio float32[O,H,W]) in the

@@ -100,3 +100,70 @@ def test_phase_a_with_same_different_bias_and_other_options(oracle):
         assert (partner[ok] == rpartner[ok]).mean() >= 0.999
     finally:
         merger.close()
+
+
+# ---- the sweep of the DEFAULT path (mn_cc_sign) pinned on its own --------------------------------------
+# Round 2 pinned phase A through mn_score_device, i.e. through the round-1 kernels; the default path's
+# sweep was covered end to end only.  mn_sweep_device exports what that sweep leaves: edge-sign masks,
+# the negative-edge list, per-lane class log-products, arg-max classes, the certificate's log sum.
+
+@pytest.mark.parametrize("shape", [(256, 512, 9, (40, 10), 0.15, 0.0, 0),
+                                   (1024, 2048, 9, (40, 10), 0.15, 0.0, 0),
+                                   (400, 667, 81, (80, 16), 0.15, 0.0, 0),      # W % 4 != 0
+                                   (96, 160, 5, (12, 6), 0.45, 0.0, 1),         # clip fused into the loads
+                                   (128, 256, 9, (40, 10), 0.25, 0.4, 1),       # same_different_bias != 0
+                                   (24, 40, 3, None, 0.12, 0.0, 1)])            # 32 offsets
+def test_default_path_sweep_equals_the_oracles_phase_a(oracle, shape):
+    import torch
+    H, W, C, oa, noise, sdb, clip = shape
+    if oa is None:
+        offs = [(di, dj) for di in range(0, 5) for dj in range(-4, 5) if di > 0 or dj > 0][:32]
+    else:
+        offs = synth.generate_offsets(*oa)
+    s = synth.synth_v1(H, W, C, offs, 1000, noise=noise, occlusion=(C == 81), num_instances=2 if oa is None else None)
+    merger = seg.Merger(H, W, C, len(offs))
+    try:
+        o = seg.default_options(same_different_bias=sdb, clip_inputs=clip)
+        cp = torch.from_numpy(np.ascontiguousarray(s.class_probs)).cuda()
+        sp = torch.from_numpy(np.ascontiguousarray(s.sameness_probs)).cuda()
+        out = merger.sweep(cp, sp, offs, o)
+        ref_cls, ref_oml, ref_prio = oracle.phase_a(s.class_probs, s.sameness_probs, C, offs, sdb, 1.0, 0.03)
+        ok = ~np.isnan(ref_oml)
+        # edges inside the float32 rounding margin of 0.5 (|log-odds| below ~2 N ulp(bias)) are neither
+        # positive nor negative for the sweep: it counts them (the image then fails the separability
+        # check); a noisy map holds a few, they are left out of the sign comparisons
+        with np.errstate(invalid="ignore"):
+            margin = ok & (np.abs(ref_oml) < 1e-4)
+        assert out["margin_edges"] <= int(margin.sum())
+        assert noise > 0.4 or out["margin_edges"] == 0
+        ok = ok & ~margin
+        bits = out["bits"].cpu().numpy().view(np.uint32)
+        # bit k set <=> the edge is in bounds and the oracle's log-odds are > 0
+        for k in range(len(offs)):
+            got = ((bits >> np.uint32(k)) & np.uint32(1)).astype(bool)
+            assert np.array_equal(got & ~margin[k], ok[k] & (ref_oml[k] > 0)), k
+        if len(offs) < 32:
+            assert not (bits >> np.uint32(len(offs))).any()          # no bit of an offset that does not exist
+        # every negative in-bounds edge is listed with the oracle's log-odds (1e-5 relative), none else
+        neg = out["neg"].cpu().numpy()
+        want = ok & (ref_oml < 0)
+        assert np.array_equal(~np.isnan(neg) & ~margin, want)
+        # (1e-5 relative; plus 1e-6 absolute, a few float32 ulps of the two logs whose difference the
+        #  log-odds are: near v = 0.5 they cancel and a purely relative bound is not meaningful)
+        err = np.abs(neg[want] - ref_oml[want]) - 1e-5 * np.abs(ref_oml[want])
+        assert err.size == 0 or err.max() <= 1e-6, err.max()
+        # certificate's sum: log max(v, 1 - v) over the in-bounds edges = -log(1 + exp(-|log-odds|))
+        want_sum = float(-np.log1p(np.exp(-np.abs(ref_oml[ok | margin].astype(np.float64)))).sum())
+        assert abs(out["logsum"] - want_sum) <= 1e-5 * abs(want_sum), (out["logsum"], want_sum)
+        assert out["pixels_per_lane"] == 4 or W % 4 != 0
+        if out["fused_class"]:
+            assert np.array_equal(out["cls"].cpu().numpy().astype(np.int32), ref_cls)      # integer-exact arg-max
+            gsum = out["gsum"].cpu().numpy().astype(np.float64) / 16777216.0               # 2^-24 fixed point
+            cpc = np.clip(s.class_probs.astype(np.float64), np.finfo(np.float32).eps, 1 - np.finfo(np.float32).eps)
+            for c in range(C):
+                want_c = float(np.log(cpc[c]).sum())
+                assert abs(gsum[c].sum() - want_c) <= 1e-6 * abs(want_c), (c, gsum[c].sum(), want_c)
+        else:
+            assert W % 4 != 0 or (H * W) % 4 != 0
+    finally:
+        merger.close()
