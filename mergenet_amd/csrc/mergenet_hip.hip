@@ -713,19 +713,22 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // negative-edge list: one region per block of the sign sweep, able to hold every edge of the block
   u64* neg_list = c->cc_neglist;
   const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
-  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+  // the sweep takes 4 pixels per lane whenever the planes stay 16-byte aligned (N % 4 == 0): with
+  // W % 4 != 0 one lane per row runs over the row's end (mn_cc_sign: `straddle`)
+  const bool sweep4 = (N & 3) == 0;
+  const size_t sign_blocks = grid_for((size_t)(sweep4 ? N / 4 : N), MN_CC_SIGN_THREADS);
   c->cc_sign_blocks = (int)sign_blocks;
-  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);   // per block
+  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (sweep4 ? 4 : 1) * (size_t)P.O);   // per block
   // class range of the components: `root` and `mapbuf` are free until the output stage
   int* clsmin = c->root;
   int* clsmax = c->mapbuf;
   // (ev[0], recorded by run_phase_a right before, is the start of the sweep: every event on the
   // caller's stream costs a ~6 us dispatch gap)
   // the sweep takes the class planes too when a lane's four pixels are four pixels of the image
-  const bool fused_cls = four && (N & 3) == 0;
+  const bool fused_cls = sweep4;
   // (pure components mode: the roots' class and validity flag are set by mn_cc_finish)
   const bool lean_cls = fused_cls && !cores;
-  if (four) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls, nullptr, nullptr, lean_cls);
+  if (sweep4) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls, nullptr, nullptr, lean_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
   if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
@@ -1651,9 +1654,9 @@ extern "C" int mn_sweep_device(mn_context* c, const float* d_class_pred, int cla
   c->debug_flags = opts->debug_flags | 2;          // (no events)
   c->ext_events = 0;
   c->cc_clean = 0;
-  const bool four = P.W % 4 == 0;
-  const bool fused_cls = four && (N & 3) == 0;
-  const size_t sign_blocks = grid_for((size_t)(four ? (N + 3) / 4 : N), MN_CC_SIGN_THREADS);
+  const bool four = (N & 3) == 0;               // (4 pixels per lane: also with W % 4 != 0, see run_components)
+  const bool fused_cls = four;
+  const size_t sign_blocks = grid_for((size_t)(four ? N / 4 : N), MN_CC_SIGN_THREADS);
   const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);
   MN_HIP(hipMemsetAsync(c->scalars, 0, MN_NSCALARS * sizeof(int), st));
   if (four) launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist, neg_cap, fused_cls);

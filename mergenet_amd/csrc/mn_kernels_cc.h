@@ -190,21 +190,29 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
   // every pixel of every lane of this wave has all offsets' columns inside the image?
   const bool colsafe = live && c0 + P.djmin >= 0 && c0 + PX - 1 + P.djmax < P.W;
   const bool fast = __all(colsafe);
+  // W % 4 != 0 (with N % 4 == 0): the four pixels of one lane per row run over the row's end into the
+  // next row -- its planes are still read by aligned 16-byte loads, the bounds tests take each pixel's
+  // own row (such a lane is never `colsafe`, so only the slow branch below sees it)
+  const bool straddle = PX == 4 && live && c0 + PX - 1 >= P.W;
   unsigned rowmask = 0u;                                 // offsets whose row is inside the image
   for (int k0 = 0; k0 < P.O; k0 += G) {
     float v[G][PX];
     int first[G];                                       // column of the first neighbour, or INT_MIN
+    int rin[G];                                         // bit 0: the lane's row + di is inside, bit 1: the next row + di
 #pragma unroll
     for (int g = 0; g < G; g++) {
       const int k = k0 + g;
       first[g] = INT_MIN;
+      rin[g] = 0;
 #pragma unroll
       for (int j = 0; j < PX; j++) v[g][j] = 1.0f;      // neutral: factor 1, its bits are masked off
       if (live && k < P.O) {
         const int rr = r + P.di[k];
-        if (rr >= 0 && rr < P.H) {
+        const bool in1 = rr >= 0 && rr < P.H, in2 = straddle && rr + 1 >= 0 && rr + 1 < P.H;
+        if (in1 || in2) {
           first[g] = c0 + P.dj[k];
-          rowmask |= 1u << k;
+          rin[g] = (in1 ? 1 : 0) | (in2 ? 2 : 0);
+          if (in1) rowmask |= 1u << k;
           if (PX == 4) {
             const float4 t = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
             v[g][0] = t.x; v[g][1 % PX] = t.y; v[g][2 % PX] = t.z; v[g][3 % PX] = t.w;
@@ -236,8 +244,11 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
         const unsigned bit = (k0 + g < P.O) ? (1u << ((k0 + g) & 31)) : 0u;
 #pragma unroll
         for (int j = 0; j < PX; j++) {
-          // first[g] == INT_MIN (row outside / no such offset) fails the column test
-          const bool inb = (unsigned)(first[g] + j) < (unsigned)P.W;
+          // first[g] == INT_MIN (row outside / no such offset) fails the column test; a pixel past the
+          // row's end belongs to the next row (straddling lane)
+          const bool second = straddle && c0 + j >= P.W;
+          const bool inb = ((rin[g] >> (second ? 1 : 0)) & 1) &&
+                           (unsigned)(first[g] + j - (second ? P.W : 0)) < (unsigned)P.W;
           const float x = inb ? mn_cc_value<PLAIN>(P, v[g][j]) : 1.0f;
           inmask[j] |= inb ? bit : 0u;
           m[j] |= (x >= P.sep_hi) ? bit : 0u;
@@ -403,9 +414,9 @@ __global__ __launch_bounds__(MN_CC_TILE_ROWS * 64) void mn_cc_tiles(ImgParams P,
   int x = t;
   while (lab[x] != x) x = lab[x];
   parent[p] = ((int)blockIdx.y * MN_CC_TILE_ROWS + (x >> 6)) * P.W + (int)blockIdx.x * 64 + (x & 63);
-  osize[p] = 0;
   cand[p] = (x == t) ? 1 : 0;               // the only pixels that can be a component root
   if (x == t) {
+    osize[p] = 0;                           // (sizes are only ever read at roots: 8 MB fewer to write)
     for (int c = 0; c < P.C; c++) lp_acc[(size_t)c * P.N + p] = 0;
     clsmin[p] = 255;
     clsmax[p] = 0;

@@ -7,7 +7,7 @@ for name in ("cseg_synth_800x1333_cfg5", "cseg_synth_400x667_c81"):
     H, W = g["mask"].shape
     ctx = seg.HostContext(H, W, g["class_probs"].shape[0], g["sameness_probs"].shape[0])
     for mode in (seg.MN_MODE_AUTO, seg.MN_MODE_ROUNDS):
-        o = seg.default_options(merge_logprob_bias=g["spec"]["opts"][2], mode=mode, clip_inputs=1)
+        o = seg.default_options(merge_logprob_bias=g["spec"]["opts"][2], mode=mode, clip_inputs=1, require_proof=-1)
         ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         print(name, "mode", mode, "used", st["mode_used"], "equal", labels.masks_equivalent(mask, classes, g["mask"], g["object_class"]),
