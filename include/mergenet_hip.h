@@ -318,6 +318,10 @@ int mn_pack_runs_device(mn_context* ctx, const int* d_mask, const int* d_object_
                         int* d_wire, void* stream);
 int mn_unpack_runs_device(const int* d_wire, int n_pixels, int capacity, int max_instances,
                           int* d_mask, int* d_table, void* stream);
+/* The same for `count` wires in ONE launch (the gathered wires of all ranks): wire i starts at
+ * d_wires + i * wire_stride_words, mask i at d_masks + i * n_pixels, table i at d_tables + i * max_instances. */
+int mn_unpack_runs_batch_device(const int* d_wires, long long wire_stride_words, int count, int n_pixels,
+                                int capacity, int max_instances, int* d_masks, int* d_tables, void* stream);
 
 int mn_last_status(void);
 const char* mn_status_string(int status);

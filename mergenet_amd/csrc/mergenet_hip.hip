@@ -48,7 +48,10 @@ static thread_local int g_last_status = MN_OK;
 struct mn_context {
   int device;
   int maxH, maxW, maxC, maxO;
-  size_t N, Rmax, cap;
+  size_t N, Rmax, cap;    // cap: slots of the record table / entries of the record lists CURRENTLY allocated
+  size_t cap_full;        // ... and what the general rounds need (allocated on their first use: ensure_general)
+  int gen_ready;
+  size_t gen_bytes;
   size_t cc_cap;          // table capacity used by the last component contraction
   int debug_flags;        // mn_options.debug_flags of the call in progress
   size_t bytes;
@@ -266,8 +269,40 @@ extern "C" const char* mn_status_string(int s) {
 
 extern "C" const char* mn_version(void) { return "mergenet_hip 0.1 (gfx950)"; }
 
+// record lists A / B, the record table and the finisher's scratch list, `cap` entries each
+static int alloc_records(mn_context* c, size_t cap) {
+  const size_t before = c->bytes;
+  MN_HIP(dev_alloc(c, &c->LA.key, cap));
+  MN_HIP(dev_alloc(c, &c->LA.S, cap));
+  MN_HIP(dev_alloc(c, &c->LA.st, cap));
+  MN_HIP(dev_alloc(c, &c->LA.fr, cap));
+  MN_HIP(dev_alloc(c, &c->LA.aux, cap));
+  MN_HIP(dev_alloc(c, &c->LB.key, cap));
+  MN_HIP(dev_alloc(c, &c->LB.S, cap));
+  MN_HIP(dev_alloc(c, &c->LB.st, cap));
+  MN_HIP(dev_alloc(c, &c->LB.fr, cap));
+  MN_HIP(dev_alloc(c, &c->LB.aux, cap));
+  MN_HIP(dev_alloc(c, &c->touched_list, cap));
+  MN_HIP(dev_alloc(c, &c->T.key, cap));
+  MN_HIP(dev_alloc(c, &c->T.S, cap));
+  MN_HIP(dev_alloc(c, &c->T.st, cap));
+  MN_HIP(dev_alloc(c, &c->T.touched, cap));
+  c->gen_bytes = c->bytes - before;
+  return MN_OK;
+}
+
+static void free_records(mn_context* c) {
+  void* dev[] = {c->LA.key, c->LA.S, c->LA.st, c->LA.fr, c->LA.aux, c->LB.key, c->LB.S, c->LB.st, c->LB.fr, c->LB.aux,
+                 c->touched_list, c->T.key, c->T.S, c->T.st, c->T.touched};
+  for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
+    if (dev[i]) (void)hipFree(dev[i]);
+  c->LA = RecList(); c->LB = RecList(); c->T = HashTab(); c->touched_list = nullptr;
+  c->bytes -= c->gen_bytes;
+  c->gen_bytes = 0;
+}
+
 static int ctx_alloc(mn_context* c) {
-  const size_t N = c->N, R = c->Rmax, cap = c->cap;
+  const size_t N = c->N, R = c->Rmax;
   MN_HIP(dev_alloc(c, &c->ocls, N));
   MN_HIP(dev_alloc(c, &c->cls0, N));
   MN_HIP(dev_alloc(c, &c->lpvalid, N));
@@ -283,30 +318,21 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->lp_acc, N * (size_t)c->maxC));
   MN_HIP(dev_alloc(c, &c->ball, N));
   MN_HIP(dev_alloc(c, &c->bsub, N));
-  MN_HIP(dev_alloc(c, &c->LA.key, R));
-  MN_HIP(dev_alloc(c, &c->LA.S, R));
-  MN_HIP(dev_alloc(c, &c->LA.st, R));
-  MN_HIP(dev_alloc(c, &c->LB.key, R));
-  MN_HIP(dev_alloc(c, &c->LB.S, R));
-  MN_HIP(dev_alloc(c, &c->LB.st, R));
-  MN_HIP(dev_alloc(c, &c->LA.fr, R));
-  MN_HIP(dev_alloc(c, &c->LA.aux, R));
-  MN_HIP(dev_alloc(c, &c->LB.fr, R));
-  MN_HIP(dev_alloc(c, &c->LB.aux, R));
-  MN_HIP(dev_alloc(c, &c->touched_list, R));
   MN_HIP(dev_alloc(c, &c->fin_lists, 3 * (size_t)MN_FIN2_MAXR));
   c->cc_cap_max = next_pow2(N / 8 + 8192);
-  if (c->cc_cap_max > cap) c->cc_cap_max = cap;
+  if (c->cc_cap_max > c->cap_full) c->cc_cap_max = c->cap_full;
   MN_HIP(dev_alloc(c, &c->cc_tcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->cc_lcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->cc_bits, N));
   MN_HIP(dev_alloc(c, &c->cc_roots, N));
   MN_HIP(dev_alloc(c, &c->cc_negcnt, N / MN_CC_SIGN_THREADS + 2));
   MN_HIP(dev_alloc(c, &c->cc_neglist, R + ((size_t)c->maxW / 64 + 2) * 1024 * (size_t)c->maxO));
-  MN_HIP(dev_alloc(c, &c->T.key, cap));
-  MN_HIP(dev_alloc(c, &c->T.S, cap));
-  MN_HIP(dev_alloc(c, &c->T.st, cap));
-  MN_HIP(dev_alloc(c, &c->T.touched, cap));
+  // record lists and record table: sized for what the speculative components attempt can use (records
+  // BETWEEN components: at most cc_cap_max); the general rounds, which hold a record per pixel edge,
+  // get theirs at first use (ensure_general) -- 0.3 instead of 2.1 GB per 1024x2048 context, and a ring
+  // of eight of them is what a throughput loop keeps
+  c->cap = c->cc_cap_max;
+  if (alloc_records(c, c->cap) != MN_OK) return MN_ERR_NO_DEVICE;
   MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
   MN_HIP(dev_alloc(c, &c->wire_counts, N / MN_RLE_ITEMS + 4));
   MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
@@ -370,7 +396,7 @@ extern "C" mn_context* mn_create(int device, int max_height, int max_width, int 
   c->maxH = max_height; c->maxW = max_width; c->maxC = max_classes; c->maxO = max_offsets;
   c->N = (size_t)max_height * max_width;
   c->Rmax = c->N * (size_t)max_offsets;
-  c->cap = next_pow2(c->Rmax + c->Rmax / 4 + 1024);
+  c->cap_full = next_pow2(c->Rmax + c->Rmax / 4 + 1024);
   if (ctx_alloc(c) != MN_OK) { mn_destroy(c); return NULL; }
   g_last_status = MN_OK;
   return c;
@@ -380,13 +406,13 @@ extern "C" void mn_destroy(mn_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
-                 c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->LA.key, c->LA.S, c->LA.st,
-                 c->LB.key, c->LB.S, c->LB.st, c->LA.fr, c->LA.aux, c->LB.fr, c->LB.aux, c->touched_list, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist, c->T.key,
-                 c->T.S, c->T.st, c->T.touched, c->block_count, c->wire_counts, c->partial, c->statblk,
+                 c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist,
+                 c->block_count, c->wire_counts, c->partial, c->statblk,
                  c->bg_key, c->gmax, c->touch, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   x_free(c);
+  free_records(c);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   if (c->h_touch) (void)hipHostFree(c->h_touch);
   for (int i = 0; i < 12; i++)
@@ -403,6 +429,25 @@ extern "C" void mn_destroy(mn_context* c) {
 }
 
 extern "C" size_t mn_workspace_bytes(const mn_context* c) { return c ? c->bytes : 0; }
+
+// The general rounds (and the small-list exact mode) hold a record per pixel edge: their lists and table
+// are allocated when first needed.  Recorded replay graphs hold the old pointers and are dropped.
+static int ensure_general(mn_context* c) {
+  if (c->gen_ready) return MN_OK;
+  MN_HIP(hipDeviceSynchronize());
+  free_records(c);
+  if (alloc_records(c, c->cap_full) != MN_OK) return MN_ERR_NO_DEVICE;
+  c->cap = c->cap_full;
+  c->gen_ready = 1;
+  c->cc_clean = 0;
+  mn_context::Replay& rp = c->replay;
+  if (rp.eA) { (void)hipGraphExecDestroy(rp.eA); rp.eA = nullptr; }
+  if (rp.eB) { (void)hipGraphExecDestroy(rp.eB); rp.eB = nullptr; }
+  if (rp.gA) { (void)hipGraphDestroy(rp.gA); rp.gA = nullptr; }
+  if (rp.gB) { (void)hipGraphDestroy(rp.gB); rp.gB = nullptr; }
+  rp.state = 0;
+  return MN_OK;
+}
 
 // ---- argument checking shared by the entry points ---------------------------------------------
 static int check_args(const mn_context* c, int class_dim, int offset_dim, int W, int H,
@@ -1106,6 +1151,11 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   fills.add(c->cnt, sizeof(Counters), 0);
   fills.add(c->scalars, MN_NSCALARS * sizeof(int), 0);
   speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
+  // everything but the speculative components attempt and the exact engine works on full-size record lists
+  if (!speculate && !xengine) {
+    rc = ensure_general(c);
+    if (rc != MN_OK) return rc;
+  }
   if (mode != MN_MODE_COMPONENTS)
     fills.add(c->mapbuf, (size_t)N * sizeof(int), 0xFF);    // (object -> record) map of mn_finisher
   if (mode == MN_MODE_COMPONENTS) {
@@ -1751,7 +1801,10 @@ extern "C" void c_run_segmentation(float* class_pred, int class_dim, float* adj_
                                    int img_width, int img_height, int num_classes, int* offset_list,
                                    int* output, int* object_class, float same_different_bias,
                                    float object_merge_factor, float merge_logprob_bias) {
-  static thread_local mn_context* cached = NULL;
+  // (freed when the thread ends: thread-local objects are destroyed before the HIP runtime's statics)
+  struct Cached { mn_context* c = NULL; ~Cached() { if (c) mn_destroy(c); } };
+  static thread_local Cached holder;
+  mn_context*& cached = holder.c;
   if (img_width <= 0 || img_height <= 0 || num_classes <= 0 || offset_dim <= 0) {
     g_last_status = MN_ERR_ARGUMENT;
     fprintf(stderr, "c_run_segmentation: %s\n", mn_status_string(MN_ERR_ARGUMENT));
@@ -1937,18 +1990,27 @@ extern "C" int mn_pack_runs_device(mn_context* c, const int* d_mask, const int* 
   return MN_OK;
 }
 
-extern "C" int mn_unpack_runs_device(const int* d_wire, int n_pixels, int capacity, int max_instances,
-                                     int* d_mask, int* d_table, void* stream) {
-  if (!d_wire || !d_mask || n_pixels <= 0 || capacity <= 0 || max_instances <= 0) {
+extern "C" int mn_unpack_runs_batch_device(const int* d_wires, long long wire_stride_words, int count,
+                                           int n_pixels, int capacity, int max_instances, int* d_masks,
+                                           int* d_tables, void* stream) {
+  if (!d_wires || !d_masks || n_pixels <= 0 || capacity <= 0 || max_instances <= 0 || count <= 0 || count > 65535 ||
+      wire_stride_words < (long long)mn_runs_wire_words(capacity, max_instances)) {
     g_last_status = MN_ERR_ARGUMENT;
     return MN_ERR_ARGUMENT;
   }
   const size_t threads = (size_t)n_pixels > (size_t)max_instances ? (size_t)n_pixels : (size_t)max_instances;
-  hipLaunchKernelGGL(mn_runs_unpack, dim3(grid_for(threads, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), d_wire, n_pixels, capacity, max_instances, d_mask, d_table);
+  hipLaunchKernelGGL(mn_runs_unpack, dim3(grid_for(threads, 256), (unsigned)count), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_wires, n_pixels, capacity, max_instances, d_masks, d_tables,
+                     wire_stride_words);
   MN_HIP(hipGetLastError());
   g_last_status = MN_OK;
   return MN_OK;
+}
+
+extern "C" int mn_unpack_runs_device(const int* d_wire, int n_pixels, int capacity, int max_instances,
+                                     int* d_mask, int* d_table, void* stream) {
+  return mn_unpack_runs_batch_device(d_wire, (long long)mn_runs_wire_words(capacity, max_instances), 1, n_pixels,
+                                     capacity, max_instances, d_mask, d_table, stream);
 }
 
 // ---- COCO RLE strings on the host (native twin of mergenet_amd/rle.py::from_change_points) ------

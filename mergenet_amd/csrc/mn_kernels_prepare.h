@@ -235,9 +235,15 @@ __global__ __launch_bounds__(256) void mn_runs_scatter(const int* __restrict__ m
 // the last change point at or before p (binary search), 0 before the first
 __global__ __launch_bounds__(256) void mn_runs_unpack(const int* __restrict__ wire, int N, int cap,
                                                       int max_instances, int* __restrict__ mask,
-                                                      int* __restrict__ table) {
+                                                      int* __restrict__ table, long long wire_stride) {
+  // blockIdx.y = which wire of a batch (the gathered wires of all ranks in ONE launch); a wire whose
+  // header is damaged (count beyond its capacity: a peer built with another capacity) must not send the
+  // search past its own sections
+  wire += (size_t)blockIdx.y * (size_t)wire_stride;
+  mask += (size_t)blockIdx.y * (size_t)N;
+  if (table) table += (size_t)blockIdx.y * (size_t)max_instances;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = wire[0];
+  const int n = min(wire[0], cap);
   const short* labels = reinterpret_cast<const short*>(wire + 4 + cap);
   const signed char* classes = reinterpret_cast<const signed char*>(wire + 4 + cap + (cap + 1) / 2);
   if (table && p < max_instances) table[p] = classes[p];

@@ -24,11 +24,11 @@
 
 __global__ __launch_bounds__(MN_FIN2_THREADS) void mn_cc_tail(
     ImgParams P, ObjState S, HashTab T, const int* __restrict__ tcount, RecList L,
-    int* __restrict__ lcount, int* __restrict__ maprec, int* __restrict__ lists,
+    int* __restrict__ lcount, int* maprec, int* __restrict__ lists,
     Counters* __restrict__ cnt, long long max_steps, int* __restrict__ scalars, int spec_limit,
     const unsigned char* __restrict__ cls0, const int* __restrict__ compsize,
     const int* __restrict__ rootlist, int nb_edges, const double* __restrict__ partial_edges,
-    double* __restrict__ lp_out, int want_cert, int* __restrict__ label,
+    double* __restrict__ lp_out, int want_cert, int* label,
     int* __restrict__ object_class) {
   __shared__ int s_w[MN_FIN2_WAVES];
   __shared__ int s_total, s_k;

@@ -83,6 +83,9 @@ def unpack_runs_cpu(wire, height: int, width: int, capacity: int, max_instances:
     n = int(wire[0])
     if n < 0:
         raise ValueError("run-length wire overflowed its capacity on the sending rank")
+    if n > capacity:
+        raise ValueError("run-length wire header claims %d change points, capacity is %d (a peer built with "
+                         "another capacity, or a damaged buffer)" % (n, capacity))
     pos = wire[4:4 + n].long()
     labels = wire[4 + capacity: 4 + capacity + (capacity + 1) // 2].view(torch.int16)[:n].to(torch.int32)
     N = height * width
@@ -103,13 +106,16 @@ class MaskExchange:
 
     * ``fmt="runs"`` (default): the row-major label change points of the mask -- the masks are
       piecewise constant -- with K, the class table and the log-likelihood in the same buffer:
-      397 KB per 1024x2048 image (``mn_pack_runs_device``; capacity n_pixels / 32 change points, a
-      mask with more reports -1 and ``result`` raises).  ``fmt="int16"``: one int16 per pixel
+      397 KB per 1024x2048 image (``mn_pack_runs_device``; capacity n_pixels / 32 change points; a
+      mask with more reports -1 in its header, which every rank sees, and ``result`` exchanges that one
+      submit again as an int16 map).  ``fmt="int16"``: one int16 per pixel
       (4.2 MB; ``mn_pack_wire_device``), for masks that do not compress and as the checked
       reference of the tests.  Either way ONE collective per step.
     * the collective of step i runs on the backend's own stream while the kernels of step i+1 run
       on the compute stream (``async_op``); a buffer is reused only after its collective has been
-      waited for.  ``wait_ms`` sums the host time spent waiting for collectives.
+      waited for.  ``wait_ms``: how long collectives held the loop up -- host time inside ``wait()`` (gloo
+      blocks there) plus, on the GPU, the stall of the compute stream behind each collective measured
+      by event pairs (under nccl ``wait()`` returns at once and only the stream waits).
 
         ex = MaskExchange(H, W, device, merger=merger)
         slot = ex.submit(mask, class_table, K)      # returns at once
@@ -150,8 +156,11 @@ class MaskExchange:
                      for _ in range(depth)]
         self.work = [None] * depth
         self.filled = [0] * depth          # submits packed into the slot's send buffer and not yet sent
+        self.kept = [[None] * self.batch for _ in range(depth)]   # inputs of a batch, for the int16 fallback
+        self.fallback = {}                 # (slot, pos) -> gathered int16 wires of an overflowed submit
         self.count = 0
-        self.wait_ms = 0.0
+        self._host_wait_ms = 0.0
+        self._stall_events = []            # (before, after) event pairs around work.wait() on the compute stream
         self.bytes_per_rank = self.words * (4 if fmt == "runs" else 2)
 
     def _pack(self, mask, class_table, num_instances, wire, total_logprob):
@@ -185,6 +194,9 @@ class MaskExchange:
             self.wait(slot)               # the slot's previous collective (results of it are gone after this)
         self._pack(mask, class_table, num_instances,
                    self.send[slot][pos * self.words:(pos + 1) * self.words], total_logprob)
+        if self.fmt == "runs":
+            self.kept[slot][pos] = (mask, class_table, num_instances, total_logprob)
+            self.fallback.pop((slot, pos), None)
         self.filled[slot] = pos + 1
         if pos == self.batch - 1:
             self._launch(slot)
@@ -209,10 +221,63 @@ class MaskExchange:
                 self.count += (self.batch - self.count % self.batch) % self.batch
         if self.work[slot] is not None:
             import time
+            # How long the exchange holds the loop up.  With gloo (CPU tensors) wait() blocks the host and
+            # the host time is the answer.  With nccl (= RCCL) wait() only makes the CURRENT STREAM wait for
+            # the collective and returns at once, so host time would say "0" whatever happens: the stall
+            # is the time between two events recorded on the compute stream around the wait.
             t = time.perf_counter()
+            cuda = self.send[slot].is_cuda
+            if cuda:
+                a = self.torch.cuda.Event(enable_timing=True)
+                b = self.torch.cuda.Event(enable_timing=True)
+                a.record()
             self.work[slot].wait()
-            self.wait_ms += (time.perf_counter() - t) * 1e3
+            if cuda:
+                b.record()
+                self._stall_events.append((a, b))
+            self._host_wait_ms += (time.perf_counter() - t) * 1e3
             self.work[slot] = None
+
+    @property
+    def wait_ms(self) -> float:
+        """Milliseconds the loop was held up by collectives so far: host time inside wait() plus, on the
+        GPU, the stall of the compute stream behind each collective (event pairs; reading it synchronises
+        with the last of them)."""
+        stall = 0.0
+        for a, b in self._stall_events:
+            b.synchronize()
+            stall += a.elapsed_time(b)
+        return self._host_wait_ms + stall
+
+    @wait_ms.setter
+    def wait_ms(self, v: float) -> None:
+        self._host_wait_ms = float(v)
+        self._stall_events = []
+
+    def _int16_fallback(self, slot: int, pos: int):
+        """A rank's mask had more label changes than the run-length wire holds (header -1, seen by every
+        rank in the gathered batch): that submit is exchanged again as an int16 map, by every rank at the
+        same point (all of them read the same headers), from the inputs kept with the batch."""
+        key = (slot, pos)
+        if key in self.fallback:
+            return self.fallback[key]
+        torch = self.torch
+        mask, table, k, lp = self.kept[slot][pos]
+        words = self.n + 1 + MAX_INSTANCES + 4
+        send = torch.empty(words, dtype=torch.int16, device=self.send[slot].device)
+        saved = self.fmt
+        self.fmt = "int16"
+        try:
+            self._pack(mask, table, k, send, lp)
+        finally:
+            self.fmt = saved
+        recv = torch.empty(self.world * words, dtype=torch.int16, device=send.device)
+        if self.world == 1:
+            recv.copy_(send)
+        else:
+            self.dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
+        self.fallback[key] = recv.view(self.world, words)
+        return self.fallback[key]
 
     def result(self, slot: int):
         """(masks [world,H,W], class tables [world,MAX_INSTANCES] padded with -1, counts [world])."""
@@ -223,15 +288,20 @@ class MaskExchange:
         if self.fmt == "int16":
             return (r[:, : self.n].view(self.world, self.H, self.W),
                     r[:, self.n + 1: self.n + 1 + MAX_INSTANCES], r[:, self.n])
-        if bool((r[:, 0] < 0).any()):
-            raise ValueError("a rank's mask has more than %d label changes: use fmt='int16'" % self.cap)
+        if bool((r[:, 0] > self.cap).any()):
+            raise ValueError("a rank's wire claims more change points than the capacity %d: peers disagree "
+                             "about the wire layout" % self.cap)
+        if bool((r[:, 0] < 0).any()):         # some rank's mask does not fit the run-length wire
+            f = self._int16_fallback(slot, pos)
+            return (f[:, : self.n].view(self.world, self.H, self.W).to(torch.int32),
+                    f[:, self.n + 1: self.n + 1 + MAX_INSTANCES].to(torch.int32), f[:, self.n].to(torch.int32))
+        if r.is_cuda:                          # every rank's wire in ONE launch
+            from . import segmenter
+            masks, tabs = segmenter.unpack_runs_batch(r, self.H, self.W, self.cap, MAX_INSTANCES)
+            return masks, tabs, r[:, 1].clone()
         masks, tabs = [], []
         for w in range(self.world):
-            if r.is_cuda:
-                from . import segmenter
-                m, t = segmenter.unpack_runs(r[w], self.H, self.W, self.cap, MAX_INSTANCES)
-            else:
-                m, t, _, _ = unpack_runs_cpu(r[w], self.H, self.W, self.cap)
+            m, t, _, _ = unpack_runs_cpu(r[w], self.H, self.W, self.cap)
             masks.append(m)
             tabs.append(t)
         return torch.stack(masks), torch.stack(tabs), r[:, 1].clone()
@@ -241,6 +311,9 @@ class MaskExchange:
         slot, pos = divmod(slot, self.batch)
         self.wait(slot)
         r = self.recv[slot].view(self.world, self.batch, self.words)[:, pos]
+        if self.fmt == "runs" and bool((r[:, 0] < 0).any()):
+            f = self._int16_fallback(slot, pos)
+            return f[:, self.n + 1 + MAX_INSTANCES:].reshape(-1).clone().view(self.torch.float64)
         if self.fmt == "runs":
             return r[:, 2:4].reshape(-1).clone().view(self.torch.float64)
         return r[:, self.n + 1 + MAX_INSTANCES:].reshape(-1).clone().view(self.torch.float64)

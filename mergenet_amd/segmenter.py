@@ -80,6 +80,7 @@ EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes"
            "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
+           "mn_unpack_runs_batch_device",
            "mn_last_status", "mn_status_string", "mn_version"]
 
 
@@ -300,6 +301,26 @@ class HostContext:
         return mask, _class_list(table), part, stats.as_dict()
 
 
+_host_contexts = {}
+
+
+def _cached_host_context(H: int, W: int, C: int, O: int) -> "HostContext":
+    """The HostContext of this shape, created on first use (at most two shapes are kept)."""
+    key = (H, W, C, O)
+    ctx = _host_contexts.get(key)
+    if ctx is None or not ctx.handle:
+        while len(_host_contexts) >= 2:
+            _host_contexts.pop(next(iter(_host_contexts))).close()
+        ctx = _host_contexts[key] = HostContext(H, W, C, O)
+    return ctx
+
+
+def close_cached_contexts() -> None:
+    """Free the contexts ObjectSegmenter keeps between calls."""
+    while _host_contexts:
+        _host_contexts.popitem()[1].close()
+
+
 class ObjectSegmenter:
     """``utils/segmenter.py:225-483`` look-alike running on the GPU (Python-variant semantics).
 
@@ -329,22 +350,21 @@ class ObjectSegmenter:
                                 merge_logprob_bias=0.0)
 
     def run_segmentation(self, prune_threshold: float = 200.0, mode: int = MN_MODE_AUTO):
-        ctx = HostContext(self.img_height, self.img_width, self.num_classes, len(self.offsets))
+        # (one context per shape is kept between calls -- creating one allocates the whole workspace,
+        #  hundreds of MB at full size, for a merge that takes a fraction of a millisecond)
+        ctx = _cached_host_context(self.img_height, self.img_width, self.num_classes, len(self.offsets))
+        o = default_options(same_different_bias=float(self.opts.same_different_bias),
+                            object_merge_factor=float(self.opts.object_merge_factor),
+                            merge_logprob_bias=float(self.opts.merge_logprob_bias),
+                            variant=MN_VARIANT_PYSEGMENTER, mode=mode,
+                            prune_threshold=float(prune_threshold))
         try:
-            o = default_options(same_different_bias=float(self.opts.same_different_bias),
-                                object_merge_factor=float(self.opts.object_merge_factor),
-                                merge_logprob_bias=float(self.opts.merge_logprob_bias),
-                                variant=MN_VARIANT_PYSEGMENTER, mode=mode,
-                                prune_threshold=float(prune_threshold))
-            try:
-                mask, classes, _, self.stats = ctx.segment(self.class_probs, self.sameness_probs,
-                                                           self.offsets, o, want_partition=False)
-            except MergeNetError as e:
-                if e.status == MN_ERR_NO_BACKGROUND:
-                    raise NameError("name 'background_obj' is not defined") from None
-                raise
-        finally:
-            ctx.close()
+            mask, classes, _, self.stats = ctx.segment(self.class_probs, self.sameness_probs,
+                                                       self.offsets, o, want_partition=False)
+        except MergeNetError as e:
+            if e.status == MN_ERR_NO_BACKGROUND:
+                raise NameError("name 'background_obj' is not defined") from None
+            raise
         return mask.astype(np.int64), classes
 
 
@@ -790,6 +810,27 @@ def pack_runs(merger, mask, class_table, num_instances: int, wire, capacity: int
                                         int(max_instances), wire.data_ptr(), ctypes.c_void_p(stream))
     if rc != 0:
         raise MergeNetError(rc)
+
+
+def unpack_runs_batch(wires, height: int, width: int, capacity: int, max_instances: int):
+    """`count` run-length wires (device, int32 [count, words], rows may be strided) -> (masks int32 [count,H,W],
+    class tables int32 [count, max_instances]) in ONE launch."""
+    import torch
+    lib = load_library()
+    count = int(wires.shape[0])
+    masks = torch.empty((count, height, width), dtype=torch.int32, device=wires.device)
+    tables = torch.empty((count, max_instances), dtype=torch.int32, device=wires.device)
+    stream = torch.cuda.current_stream(wires.device).cuda_stream
+    lib.mn_unpack_runs_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]
+    lib.mn_unpack_runs_batch_device.restype = ctypes.c_int
+    rc = lib.mn_unpack_runs_batch_device(wires.data_ptr(), int(wires.stride(0)), count, height * width,
+                                         int(capacity), int(max_instances), masks.data_ptr(), tables.data_ptr(),
+                                         ctypes.c_void_p(stream))
+    if rc != 0:
+        raise MergeNetError(rc)
+    return masks, tables
 
 
 def unpack_runs(wire, height: int, width: int, capacity: int, max_instances: int):

@@ -204,3 +204,52 @@ def test_mask_exchange_single_process_and_limits():
     assert tabs[0, :3].tolist() == [5, 7, -1] and int(counts[0]) == 2
     with pytest.raises(ValueError):
         ex.submit(mask, table, mnd.MAX_INSTANCES + 1)
+
+
+def _fallback_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, B = 16, 64, 2                   # capacity max(64, 1024 / 32) = 64 change points
+    ex = mnd.MaskExchange(H, W, torch.device("cpu"), depth=2, fmt="runs", batch=B)
+    g = torch.Generator().manual_seed(11)
+    noisy = torch.randint(0, 9, (H, W), generator=g, dtype=torch.int32)        # ~900 label changes: does not fit
+    calm = _test_mask(H, W, rank, 0)
+    ok = True
+    table = torch.arange(1, 10, dtype=torch.int32)
+    # step 0: only rank 1's mask overflows; step 1: nobody's; both in one batch
+    h0 = ex.submit(noisy if rank == 1 else calm, table, 8, -1.5 * (rank + 1))
+    h1 = ex.submit(calm, table, 3, -2.5 * (rank + 1))
+    masks, tabs, counts = ex.result(h0)       # every rank sees rank 1's header -1 and joins the int16 exchange
+    ok &= masks.shape == (world, H, W) and masks.dtype == torch.int32
+    ok &= bool((masks[1] == noisy).all()) and bool((masks[0] == _test_mask(H, W, 0, 0)).all())
+    ok &= counts.tolist() == [8, 8] and tabs[1, :8].tolist() == list(range(1, 9))
+    ok &= ex.logprobs(h0).tolist() == [-1.5, -3.0]
+    masks, tabs, counts = ex.result(h1)       # the other submit of the batch went through the run-length wire
+    ok &= all(bool((masks[r] == _test_mask(H, W, r, 0)).all()) for r in range(world))
+    ok &= counts.tolist() == [3, 3] and ex.logprobs(h1).tolist() == [-2.5, -5.0]
+    ex.drain()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_mask_exchange_overflowing_mask_falls_back_to_int16_world2_gloo():
+    """A mask with more label changes than the run-length wire holds: its header says -1, every rank sees
+    it, and that ONE submit is exchanged again as an int16 map (round 2: result() raised)."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fallback_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_run_length_wire_with_a_damaged_header_is_rejected():
+    """A header that claims more change points than the capacity (a peer built with another capacity)
+    must not send the reader past the wire's sections."""
+    H, W = 8, 16
+    cap = mnd.runs_capacity(H * W)
+    wire = mnd.pack_runs_cpu(_test_mask(H, W, 0, 0), torch.arange(1, 4, dtype=torch.int32), 3, 0.0, cap)
+    wire[0] = cap + 5
+    with pytest.raises(ValueError):
+        mnd.unpack_runs_cpu(wire, H, W, cap)

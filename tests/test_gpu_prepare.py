@@ -292,3 +292,39 @@ def test_run_length_wire_device_equals_cpu_twin_and_round_trips():
         assert int(wire[0]) == -1 and bool((wire[-8:] == 777).all())
     finally:
         merger.close()
+
+
+@pytest.mark.gpu
+def test_run_length_wires_of_all_ranks_unpack_in_one_launch():
+    """mn_unpack_runs_batch_device: the gathered wires of several ranks (rows of a strided 2-D buffer)
+    restored by ONE launch equal the one-by-one results; a wire whose header claims more change points
+    than the capacity is clamped (the search stays inside the wire's own sections)."""
+    import torch
+    from mergenet_amd import distributed as mnd
+    from mergenet_amd import segmenter as seg
+    rng = np.random.default_rng(9)
+    H, W = 40, 72
+    cap = mnd.runs_capacity(H * W)
+    words = seg.runs_wire_words(cap, mnd.MAX_INSTANCES)
+    merger = seg.Merger(H, W, 3, 2)
+    try:
+        wires = torch.zeros((3, 2, words), dtype=torch.int32, device="cuda")     # [rank, batch, words]
+        masks = []
+        for r in range(3):
+            m = np.repeat(np.repeat(rng.integers(0, 4, (5, 6)), 8, 0), 12, 1)[:H, :W].astype(np.int32)
+            masks.append(m)
+            table = torch.full((H * W,), -1, dtype=torch.int32, device="cuda")
+            table[:3] = torch.tensor([1 + r, 2 + r, 3 + r], dtype=torch.int32, device="cuda")
+            seg.pack_runs(merger, torch.from_numpy(m).cuda(), table, 3, wires[r, 1], cap, mnd.MAX_INSTANCES, -1.0 * r)
+        view = wires[:, 1]                                                         # strided rows
+        got_m, got_t = seg.unpack_runs_batch(view, H, W, cap, mnd.MAX_INSTANCES)
+        for r in range(3):
+            assert np.array_equal(got_m[r].cpu().numpy(), masks[r])
+            assert got_t[r, :3].cpu().tolist() == [1 + r, 2 + r, 3 + r] and bool((got_t[r, 3:] == -1).all())
+            one_m, one_t = seg.unpack_runs(view[r].contiguous(), H, W, cap, mnd.MAX_INSTANCES)
+            assert torch.equal(one_m, got_m[r]) and torch.equal(one_t, got_t[r])
+        view[0, 0] = cap + 1000                                                    # damaged header
+        got_m, got_t = seg.unpack_runs_batch(view, H, W, cap, mnd.MAX_INSTANCES)   # must not fault
+        assert np.array_equal(got_m[1].cpu().numpy(), masks[1])
+    finally:
+        merger.close()
