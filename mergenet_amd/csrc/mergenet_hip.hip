@@ -776,6 +776,18 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   if (sweep4) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls, nullptr, nullptr, lean_cls);
   else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
   if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
+  // debug_flags bit 11: fork right behind the sweep -- the labelling too runs on the side stream, beside
+  // the next images' sweeps (the caller's stream then carries the sweeps alone)
+  const bool early_fork = fork_before_sums && (c->debug_flags & 2048) && !c->replay.capturing && !cores;
+  if (early_fork) {
+    if (c->ext_events) {
+      MN_HIP(hipStreamWaitEvent(c->side, c->ev[10], 0));           // (the sweep's own stop event)
+    } else {
+      MN_HIP(hipEventRecord(c->ev_fork, st));
+      MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
+    st = c->side;
+  }
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
   const unsigned* lbits = c->cc_bits;
   unsigned kshort = 0u;
@@ -803,7 +815,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     st = c->replay.cap;
   }
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
-  const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing;
+  const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing && !early_fork;
   bool fork_by_hook = false;
   if (c->debug_flags & 1024) {
     // (opt-in, slower so far: 8.7 + 25 + 9 + 30 us against 59 us) labelling by row runs in 16 x 256 tiles (mn_cc_tiles2 / mn_cc_link / mn_cc_flat_roots)
@@ -857,8 +869,10 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
     // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
     // for the side stream; nothing of this image is left on the caller's stream after this point.
-    if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
-    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (!early_fork) {
+      if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
+      MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
     st = c->side;
     if (c->replay.capturing) {     // everything from here to the end of the image goes into graph B
       MN_HIP(hipStreamBeginCapture(c->replay.cap, hipStreamCaptureModeThreadLocal));

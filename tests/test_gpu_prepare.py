@@ -304,7 +304,7 @@ def test_run_length_wires_of_all_ranks_unpack_in_one_launch():
     from mergenet_amd import segmenter as seg
     rng = np.random.default_rng(9)
     H, W = 40, 72
-    cap = mnd.runs_capacity(H * W)
+    cap = 1024                                # (room for every change point of the block masks below)
     words = seg.runs_wire_words(cap, mnd.MAX_INSTANCES)
     merger = seg.Merger(H, W, 3, 2)
     try:
