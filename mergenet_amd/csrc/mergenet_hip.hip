@@ -821,8 +821,9 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     // (opt-in, slower so far: 8.7 + 25 + 9 + 30 us against 59 us) labelling by row runs in 16 x 256 tiles (mn_cc_tiles2 / mn_cc_link / mn_cc_flat_roots)
     const unsigned lanes = (unsigned)(((P.W + 3) >> 2) * P.H);
     const dim3 tiles2((P.W + MN_T2_COLS - 1) / MN_T2_COLS, (P.H + MN_T2_ROWS - 1) / MN_T2_ROWS);
+    int* dbg = getenv("MN_TRACE_LABEL") ? c->scalars + 10 : nullptr;     // [10..12]: unions asked for by the stages
     hipLaunchKernelGGL(mn_cc_tiles2, tiles2, dim3(MN_T2_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv);
-    if (kh >= 0 || kv >= 0) hipLaunchKernelGGL(mn_cc_borders2, tiles2, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv);
+    if (kh >= 0 || kv >= 0) hipLaunchKernelGGL(mn_cc_borders2, tiles2, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv, dbg);
     if (kh >= 0) kmask &= ~(1u << kh);
     if (kv >= 0) kmask &= ~(1u << kv);
     const dim3 gf(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256));
@@ -832,9 +833,9 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (kmask) {
       const dim3 gl(8 * ((grid_for(lanes, 256) + 7) / 8));
       if (fork_by_hook)
-        hipExtLaunchKernelGGL(mn_cc_link, gl, b, 0, st, nullptr, c->ev_fork, 0, P, lbits, c->parent, kh, kv, dv, kmask);
+        hipExtLaunchKernelGGL(mn_cc_link, gl, b, 0, st, nullptr, c->ev_fork, 0, P, lbits, c->parent, kh, kv, dv, kmask, dbg);
       else
-        hipLaunchKernelGGL(mn_cc_link, gl, b, 0, st, P, lbits, c->parent, kh, kv, dv, kmask);
+        hipLaunchKernelGGL(mn_cc_link, gl, b, 0, st, P, lbits, c->parent, kh, kv, dv, kmask, dbg);
     }
   } else {
   hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(MN_CC_TILE_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv,
@@ -1053,6 +1054,9 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     if (c->h_scalars[7] != 0 || c->h_cnt->n_records > finish_limit) return MN_RETRY_WAIT;
   }
   const long long merges = (long long)N - (long long)c->h_scalars[2];     // every merge removes one object
+  if (getenv("MN_TRACE_LABEL"))
+    fprintf(stderr, "labelling: unions asked for -- vertical borders %d, horizontal borders %d, other offsets %d\n",
+            c->h_scalars[10], c->h_scalars[11], c->h_scalars[12]);
   const int rc = c->h_cnt->error != 0 ? c->h_cnt->error : MN_OK;
   if (stats) {
     stats->status = rc;
@@ -1122,7 +1126,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
 
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
-  c->debug_flags = opts->debug_flags;
+  // (development aid: MN_DEBUG_FLAGS_OR in the environment is OR-ed into debug_flags, so that a whole
+  //  test run can be put through an opt-in code path)
+  static const int env_flags = getenv("MN_DEBUG_FLAGS_OR") ? atoi(getenv("MN_DEBUG_FLAGS_OR")) : 0;
+  c->debug_flags = opts->debug_flags | env_flags;
   c->ext_events = !(opts->debug_flags & 2) && !(opts->debug_flags & 128);
   c->core_radius = opts->core_radius != 0 ? opts->core_radius : MN_DEFAULT_CORE_RADIUS;
   const int N = P.N;

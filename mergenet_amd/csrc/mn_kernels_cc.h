@@ -598,6 +598,9 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
 struct __attribute__((packed, aligned(4))) mn_uint4u { unsigned x, y, z, w; };
 
 __device__ __forceinline__ int mn_dpp_prev_lane(int v) {          // lane l gets lane l-1's value, lane 0 gets 0
+#ifdef MN_LBL_NODPP
+  return 0;
+#endif
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);   // wave_shr:1
 }
 
@@ -607,6 +610,31 @@ __device__ __forceinline__ void mn_cc_unite(int* __restrict__ parent, int x, int
   while (a != b) {
     if (a < b) { const int t = a; a = b; b = t; }
     const int old = atomicMin(&parent[a], b);
+    if (old == a) break;
+    a = mn_cc_find(parent, old);
+    b = mn_cc_find(parent, b);
+  }
+}
+
+// The same with RANDOMISED linking for the stages that work on global memory: hooking "larger id under
+// smaller" builds trees as deep as the tile grid is wide and high (every tile root is asked for by its
+// left AND its upper neighbour; the loser of the race climbs the winner's chain and tries again one
+// level up), a hash of the id as linking priority keeps the expected depth logarithmic whatever the
+// order of the unions.  Nothing downstream needs the root to be the smallest pixel of its component.
+__device__ __forceinline__ unsigned mn_cc_prio(int x) {
+  unsigned h = (unsigned)x * 0x9E3779B1u;
+  h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+  return h;
+}
+__device__ __forceinline__ void mn_cc_unite_rand(int* __restrict__ parent, int x, int y) {
+#ifdef MN_LBL_NOUNITE
+  return;
+#endif
+  int a = mn_cc_find(parent, x), b = mn_cc_find(parent, y);
+  while (a != b) {
+    const unsigned ha = mn_cc_prio(a), hb = mn_cc_prio(b);
+    if (ha < hb || (ha == hb && a < b)) { const int t = a; a = b; b = t; }   // a: the larger priority goes under b
+    const int old = atomicCAS(&parent[a], a, b);
     if (old == a) break;
     a = mn_cc_find(parent, old);
     b = mn_cc_find(parent, b);
@@ -686,7 +714,7 @@ __global__ __launch_bounds__(MN_T2_ROWS * 64) void mn_cc_tiles2(ImgParams P, con
 // tile (4 per lane), wave 1 the 16 horizontal ones across its right border; repeats of the previous
 // pixel's request are dropped, so a border segment inside one pair of components costs one union
 __global__ __launch_bounds__(128) void mn_cc_borders2(ImgParams P, const unsigned* __restrict__ bits,
-                                                      int* __restrict__ parent, int kh, int kv, int dv) {
+                                                      int* __restrict__ parent, int kh, int kv, int dv, int* dbg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = (int)blockIdx.y * MN_T2_ROWS, cb = (int)blockIdx.x * MN_T2_COLS;
   if (wave == 0) {
@@ -720,7 +748,7 @@ __global__ __launch_bounds__(128) void mn_cc_borders2(ImgParams P, const unsigne
     for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[j - 1] == rq[j]);
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (go[j]) mn_cc_unite(parent, own[j], rq[j]);
+      if (go[j]) { mn_cc_unite_rand(parent, own[j], rq[j]); if (dbg) atomicAdd(dbg, 1); }
   } else {
     if (kh < 0) return;
     const int r = r0 + lane, c = cb + MN_T2_COLS - 1;
@@ -731,12 +759,12 @@ __global__ __launch_bounds__(128) void mn_cc_borders2(ImgParams P, const unsigne
     if (in && ((bits[p] >> kh) & 1u)) { own = parent[p]; rq = parent[p + 1]; req = own != rq; }
     const bool preq = mn_dpp_prev_lane(req ? 1 : 0) != 0;
     const int pown = mn_dpp_prev_lane(own), prq = mn_dpp_prev_lane(rq);
-    if (req && !(preq && pown == own && prq == rq)) mn_cc_unite(parent, own, rq);
+    if (req && !(preq && pown == own && prq == rq)) { mn_cc_unite_rand(parent, own, rq); if (dbg) atomicAdd(dbg + 1, 1); }
   }
 }
 
 __global__ __launch_bounds__(256) void mn_cc_link(ImgParams P, const unsigned* __restrict__ bits,
-                                                  int* __restrict__ parent, int kh, int kv, int dv, unsigned kmask) {
+                                                  int* __restrict__ parent, int kh, int kv, int dv, unsigned kmask, int* dbg) {
   const int lpr = (P.W + 3) >> 2, total = lpr * P.H;
   const int tile = mn_xcd_tile((total + 255) >> 8, P.banded);
   const int i = tile < 0 ? total : tile * 256 + (int)threadIdx.x;
@@ -766,36 +794,47 @@ __global__ __launch_bounds__(256) void mn_cc_link(ImgParams P, const unsigned* _
     if (!border_row) { b[0] &= ~(1u << kv); b[1] &= ~(1u << kv); b[2] &= ~(1u << kv); b[3] &= ~(1u << kv); }
   }
   const unsigned any = (b[0] | b[1] | b[2] | b[3]) & kmask;
-  for (int k = 0; k < P.O; k++) {
-    if (!((kmask >> k) & 1u)) continue;
-    if (__ballot((any >> k) & 1u) == 0) continue;                   // uniform
-    const long long q0 = (long long)(r + P.di[k]) * P.W + c0 + P.dj[k];
-    int rq[4];
+  constexpr int G = 4;                        // offsets whose loads are in flight together
+  for (int k0 = 0; k0 < P.O; k0 += G) {
+    if (__ballot((any >> k0) & ((1u << G) - 1u)) == 0) continue;    // uniform
+    int rq[G][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) rq[j] = own[j];
-    if ((any >> k) & 1u) {
-      if (q0 >= 0 && q0 + 3 < P.N) {
-        const int4 t = mn_ld_int4_unaligned(parent + q0);
-        rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w;
-      } else {
+    for (int g = 0; g < G; g++) {
+      const int k = k0 + g;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (((b[j] >> k) & 1u) && q0 + j >= 0 && q0 + j < P.N) rq[j] = parent[q0 + j];
+      for (int j = 0; j < 4; j++) rq[g][j] = own[j];
+      if (k < P.O && ((any >> k) & 1u)) {
+        const long long q0 = (long long)(r + P.di[k]) * P.W + c0 + P.dj[k];
+        if (q0 >= 0 && q0 + 3 < P.N) {
+          const int4 t = mn_ld_int4_unaligned(parent + q0);
+          rq[g][0] = t.x; rq[g][1] = t.y; rq[g][2] = t.z; rq[g][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (((b[j] >> k) & 1u) && q0 + j >= 0 && q0 + j < P.N) rq[g][j] = parent[q0 + j];
+        }
       }
     }
-    bool req[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> k) & 1u) && rq[j] != own[j];
-    // a request equal to the previous pixel's (same two sets asked for) is dropped
-    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
-    const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[3]);
-    bool go[4];
-    go[0] = req[0] && !(preq && lane != 0 && pown == own[0] && prq == rq[0]);
+    for (int g = 0; g < G; g++) {
+      const int k = k0 + g;
+      if (k >= P.O) break;                    // uniform
+      if (!((kmask >> k) & 1u)) continue;
+      bool req[4];
 #pragma unroll
-    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[j - 1] == rq[j]);
+      for (int j = 0; j < 4; j++) req[j] = ((b[j] >> k) & 1u) && rq[g][j] != own[j];
+      if (__ballot(req[0] || req[1] || req[2] || req[3]) == 0) continue;      // uniform: nearly always
+      // a request equal to the previous pixel's (same two sets asked for) is dropped
+      const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
+      const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[g][3]);
+      bool go[4];
+      go[0] = req[0] && !(preq && lane != 0 && pown == own[0] && prq == rq[g][0]);
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (go[j]) mn_cc_unite(parent, own[j], rq[j]);
+      for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[g][j - 1] == rq[g][j]);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (go[j]) { mn_cc_unite_rand(parent, own[j], rq[g][j]); if (dbg) atomicAdd(dbg + 2, 1); }
+    }
   }
 }
 
