@@ -816,7 +816,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   }
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
   const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing && !early_fork;
-  bool fork_by_hook = false;
+  bool fork_by_hook = false, mid_fork = false;
   if (c->debug_flags & 1024) {
     // (opt-in, slower so far: 8.7 + 25 + 9 + 30 us against 59 us) labelling by row runs in 16 x 256 tiles (mn_cc_tiles2 / mn_cc_link / mn_cc_flat_roots)
     const unsigned lanes = (unsigned)(((P.W + 3) >> 2) * P.H);
@@ -845,9 +845,16 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (kh >= 0) kmask &= ~(1u << kh);
     if (kv >= 0) kmask &= ~(1u << kv);
   }
+  // debug_flags bit 12: fork behind the border stage -- flatten and hook join the side stream
+  if (fork_before_sums && (c->debug_flags & 4096) && !c->replay.capturing && !cores && !early_fork) {
+    MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    st = c->side;
+    mid_fork = true;
+  }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
   // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
-  fork_by_hook = fork_ext && kmask;
+  fork_by_hook = fork_ext && kmask && !mid_fork;
   if (kmask) {
     if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
     else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
@@ -870,7 +877,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
     // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
     // for the side stream; nothing of this image is left on the caller's stream after this point.
-    if (!early_fork) {
+    if (!early_fork && !mid_fork) {
       if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
       MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }

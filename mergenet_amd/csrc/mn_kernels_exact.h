@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
     unsigned newp = 0;
     int newcap = 0;
     if (la + lb > capa) {
-      newcap = ((3 * (la + lb) + 63) / 64) * 64;
+      newcap = ((4 * (la + lb) + 63) / 64) * 64;
       if (bump + (unsigned long long)newcap > X.arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
       newp = (unsigned)bump;
       bump += (unsigned long long)newcap;
