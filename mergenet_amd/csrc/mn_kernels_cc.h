@@ -93,6 +93,34 @@ __device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) 
 #define MN_CC_SIGN_G 5           /* offsets whose loads are in flight together */
 #define MN_CC_EDGE_PIXBITS 26    /* components mode serves N <= 2^26 */
 
+// Streaming accesses of the sweep: every plane value is read once and every output written once, so the
+// loads / stores may carry the non-temporal hint (-DMN_NT_LOADS / -DMN_NT_STORES: measured)
+typedef float mn_f4v __attribute__((ext_vector_type(4)));
+typedef unsigned mn_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 mn_ld_stream4(const float* p) {
+#ifdef MN_NT_LOADS
+  const mn_f4v t = __builtin_nontemporal_load(reinterpret_cast<const mn_f4v*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void mn_st_stream(int* p, int v) {
+#ifdef MN_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void mn_st_stream(uint4* p, uint4 v) {
+#ifdef MN_NT_STORES
+  mn_u4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<mn_u4v*>(p));
+#else
+  *p = v;
+#endif
+}
+
 template <bool PLAIN>
 __device__ __forceinline__ float mn_cc_value(const ImgParams& P, float v) {
   return PLAIN ? v : mn_same_value(P, v);
@@ -128,11 +156,11 @@ __device__ __forceinline__ void mn_cc_class_part(const ImgParams& P, const ClsOu
   // of the reference it stands for).
   float4 best, prev = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
   int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  float4 nxt = *reinterpret_cast<const float4*>(P.cls + 4 * (size_t)i);
+  float4 nxt = mn_ld_stream4(P.cls + 4 * (size_t)i);
   for (int c = 0; c < P.C; c++) {
     float4 v = nxt;
     if (c + 1 < P.C)
-      nxt = *reinterpret_cast<const float4*>(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
+      nxt = mn_ld_stream4(P.cls + (size_t)(c + 1) * P.N + 4 * (size_t)i);
     if (P.clip) { v.x = mn_clip(v.x); v.y = mn_clip(v.y); v.z = mn_clip(v.z); v.w = mn_clip(v.w); }
     if (c == 0) {
       best = v;
@@ -143,7 +171,7 @@ __device__ __forceinline__ void mn_cc_class_part(const ImgParams& P, const ClsOu
       if (v.w > best.w) { prev.w = best.w; best.w = v.w; b3 = c; }
     }
     // float * 2^24 is exact: the term is the exact product rounded to the nearest integer
-    CO.gsum[(size_t)c * CO.gstride + i] = __float2int_rn(logf((v.x * v.y) * (v.z * v.w)) * 16777216.0f);
+    mn_st_stream(&CO.gsum[(size_t)c * CO.gstride + i], __float2int_rn(logf((v.x * v.y) * (v.z * v.w)) * 16777216.0f));
   }
   // a lower class within 2^-18 of the maximum (logs of magnitude < 16 are 2^-20 apart at most, and
   // the GPU's logf is within an ulp of libm's): settle it the reference's way
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
           rin[g] = (in1 ? 1 : 0) | (in2 ? 2 : 0);
           if (in1) rowmask |= 1u << k;
           if (PX == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(P.same + (size_t)k * P.N + p0);
+            const float4 t = mn_ld_stream4(P.same + (size_t)k * P.N + p0);
             v[g][0] = t.x; v[g][1 % PX] = t.y; v[g][2 % PX] = t.z; v[g][3 % PX] = t.w;
           } else {
             v[g][0] = P.same[(size_t)k * P.N + p0];
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
     bad += __popc(in & ~(m[j] | ng[j]));                // inside the rounding margin of 0.5
   }
   if (live) {
-    if (PX == 4) *reinterpret_cast<uint4*>(bits + p0) = make_uint4(m[0], m[1 % PX], m[2 % PX], m[3 % PX]);
+    if (PX == 4) mn_st_stream(reinterpret_cast<uint4*>(bits + p0), make_uint4(m[0], m[1 % PX], m[2 % PX], m[3 % PX]));
     else bits[p0] = m[0];
   }
   // block scan of the lanes' negative-edge counts
