@@ -169,7 +169,7 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
 // ---- exact engine: workspace ------------------------------------------------------------------------
 static void x_free(mn_context* c) {
   XState& X = c->xw.X;
-  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl};
+  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl, X.mlog};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
@@ -233,6 +233,11 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   X.NL = (unsigned)NL;
   X.cap0 = cap0;
   X.parent = c->parent;
+  // diagnostic: MN_X_MERGELOG=<file> keeps the sequence of merges (survivor, absorbed, record, priority)
+  if (getenv("MN_X_MERGELOG") && !X.mlog) {
+    if (hipMalloc(reinterpret_cast<void**>(&X.mlog), (size_t)N * 16) == hipSuccess) X.mlog_cap = N;
+    else X.mlog = nullptr;
+  }
   return MN_OK;
 }
 
@@ -1027,6 +1032,16 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
       fprintf(stderr, "  stamp %-14s %12lld cycles %5.1f%%\n", nm[i], w.h_ctl->stamps[i], 100.0 * w.h_ctl->stamps[i] / (tot ? tot : 1));
   }
 #endif
+  if (const char* path = getenv("MN_X_MERGELOG")) {
+    if (X.mlog && w.h_ctl->merges > 0) {
+      const size_t n = (size_t)(w.h_ctl->merges < X.mlog_cap ? w.h_ctl->merges : X.mlog_cap);
+      int* h = static_cast<int*>(malloc(n * 16));
+      if (h && hipMemcpy(h, X.mlog, n * 16, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(path, "wb")) { fwrite(h, 16, n, f); fclose(f); }
+      }
+      free(h);
+    }
+  }
   // what the output stage reads: class sums of the survivors (plane-major), step counters
   hipLaunchKernelGGL(mn_x_export_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->osize, c->ocls,
                      c->lpsum, c->lpvalid);

@@ -90,6 +90,8 @@ struct XState {
   int Blog, NB, NBpad, NG;
   unsigned NL;                // record ids in use (N * O)
   int cap0;                   // arena entries every pixel starts with
+  int* mlog;                  // diagnostic (MN_X_MERGELOG): 4 ints per merge {survivor, absorbed, record, priority bits}
+  long long mlog_cap;         // merges the log holds (0: none)
   XCtl* ctl;
 };
 
@@ -532,6 +534,12 @@ __global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long 
       newp = (unsigned)bump;
       bump += (unsigned long long)newcap;
       moved = true;
+    }
+    if (X.mlog_cap > 0 && lane == 0) {
+      const long long at = X.ctl->merges + merges;
+      if (at < X.mlog_cap) {
+        X.mlog[4 * at] = a; X.mlog[4 * at + 1] = b; X.mlog[4 * at + 2] = (int)rid; X.mlog[4 * at + 3] = (int)(gword - 1u);
+      }
     }
     merges++;
     // object state of the survivor (:635-642); the absorbed object only keeps its parent link

@@ -131,6 +131,11 @@ def cseg_specs(big: bool):
                       seed=8001, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
     specs.append(dict(name="cseg_checker_96x128_b015", kind="checker", H=96, W=128, C=3,
                       offsets=[6, 4], seed=4, cell_px=4, opts=(0.0, 1.0, 0.15)))
+    # (round 3) a stronger blur carries the out-of-image sameness value 1.0 into the maps near the image
+    # border, where it is clipped to 0.99: bit-equal priorities whose ORDER decides the result
+    for sd in (5100, 5103):
+        specs.append(dict(name="cseg_blur4_128x256_s%d" % sd, kind="blur", H=128, W=256, C=9, offsets=[40, 10],
+                          seed=sd, radius=4, noise=0.05, opts=(0.0, 1.0, 0.03)))
     if big:
         specs.append(dict(name="cseg_blur_256x512_r2", kind="blur", H=256, W=512, C=9,
                           offsets=[40, 10], seed=8000, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))

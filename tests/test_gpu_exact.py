@@ -60,7 +60,8 @@ def test_exact_phase_a_is_bit_identical_to_the_oracle(oracle, shape):
 
 
 # ---- the order itself ----------------------------------------------------------------------------------
-ALL_CSEG = [n for n in gu.names("cseg_") if not any(t in n for t in ("1024x2048", "800x1333"))]
+TIE_DECIDED = gu.names("cseg_blur4_")
+ALL_CSEG = [n for n in gu.names("cseg_") if not any(t in n for t in ("1024x2048", "800x1333")) and n not in TIE_DECIDED]
 
 
 @pytest.mark.parametrize("name", ALL_CSEG)
@@ -73,6 +74,31 @@ def test_exact_engine_equals_the_reference_on_every_vector(oracle, name):
     assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] >= 1
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
     assert st["merges"] == g["spec"]["H"] * g["spec"]["W"] - st["num_objects"]
+
+
+@pytest.mark.xfail(strict=True, reason="the one documented difference of the exact engine: the ORDER among bit-equal "
+                   "priorities.  A radius-4 blur carries the out-of-image sameness value 1.0 into the maps near the "
+                   "image border, where it is clipped to 0.99, so the queue starts with runs of equal keys; the "
+                   "reference pops them in the order its std::priority_queue's heap mechanics and unordered_map "
+                   "iteration produce (segment.h:237-242, segment.cc:650-652), the engine by lowest record id.  The "
+                   "CPU model of the reference's semantics WITH the engine's rule gives the engine's event count "
+                   "exactly (DESIGN.md section 5), i.e. the difference is the tie rule and nothing else.")
+@pytest.mark.parametrize("name", TIE_DECIDED)
+def test_exact_engine_on_inputs_decided_by_tie_order(oracle, name):
+    g = gu.load(name)
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+@pytest.mark.parametrize("name", TIE_DECIDED)
+def test_exact_engine_stays_close_where_tie_order_decides(oracle, name):
+    """... and a floor under it: the partitions agree on at least 98.5 % of the pixels (measured 98.9-99.99 %
+    on eight such images, tests/tools/gpu_exact_campaign.py) and differ by at most one instance."""
+    from mergenet_amd import labels
+    g = gu.load(name)
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    assert abs(len(classes) - len(g["object_class"])) <= 1
+    assert labels.agreement(mask, g["mask"]) >= 0.985 * mask.size, st
 
 
 def test_exact_engine_blurred_256x512_within_ten_seconds(oracle):
