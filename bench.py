@@ -441,7 +441,9 @@ def main():
     if rank == 0:
         plane_bytes = 4.0 * H * W
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_components_1024x2048.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_components_1024x2048.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_components_1024x2048.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh).get("hbm_bytes_per_launch", {})
@@ -479,7 +481,7 @@ def main():
                     "algorithmic_bytes": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_launch_ms"],
                     "timing": "hipEvent pair attached to the kernel's own dispatch on the launch stream "
                               "(hipExtLaunchKernel start/stop events) in EVERY timed step; rocprofv3 "
-                              "durations of the same loop are in profiles/r02_bench_kernel_stats.csv; "
+                              "durations of the same loop are in profiles/r03_bench_kernel_stats.csv; "
                               "the other phases' events are recorded "
                               "in one step of %d, because events are host work and the host must not "
                               "become the bottleneck of the loop" % EVENTS_EVERY,

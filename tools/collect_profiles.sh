@@ -19,3 +19,20 @@ W=$(ls gpurun_out/${TAG}_pmc_5/*counter_collection.csv gpurun_out/${TAG}_pmc_5/*
 cp "$F" gpurun_out/$TAG/pmc_fetch_components_counter_collection.csv
 cp "$W" gpurun_out/$TAG/pmc_write_components_counter_collection.csv
 python tools/pmc_summary.py "$F" "$W" gpurun_out/$TAG/pmc_components_1024x2048.json
+# configs[4]: the fused four-pixel sweep at W % 4 != 0 (kernel stats + HBM bytes of the sweep)
+cd /tmp && export TMPDIR=/tmp
+rm -rf $ROOT/gpurun_out/${TAG}_cfg5 && mkdir -p $ROOT/gpurun_out/${TAG}_cfg5
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_cfg5 -o run -- python3 $ROOT/tools/prof_cfg5.py 10 > $ROOT/gpurun_out/$TAG/cfg5_stdout.log 2>&1
+cp $(find $ROOT/gpurun_out/${TAG}_cfg5 -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/$TAG/cfg5_kernel_stats.csv
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $ROOT/gpurun_out/${TAG}_cfg5_$cnt
+  rocprofv3 --pmc $cnt --output-format csv -d $ROOT/gpurun_out/${TAG}_cfg5_$cnt -o run -- python3 $ROOT/tools/prof_cfg5.py 3 > /dev/null 2>&1
+done
+python3 $ROOT/tools/pmc_summary.py $(find $ROOT/gpurun_out/${TAG}_cfg5_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $ROOT/gpurun_out/${TAG}_cfg5_WRITE_SIZE -name '*counter_collection.csv' | head -1) $ROOT/gpurun_out/$TAG/pmc_cfg5_800x1333.json > /dev/null
+# the exact engine: kernel stats of one 512x1024 image and one blurred 256x512 map
+rm -rf $ROOT/gpurun_out/${TAG}_exact && mkdir -p $ROOT/gpurun_out/${TAG}_exact
+MN_TRACE_EXACT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_exact -o run -- python3 $ROOT/tests/tools/gpu_exact.py 600000 512x1024_s1000 blur_256x512 > $ROOT/gpurun_out/$TAG/exact_stdout.log 2>&1
+cp $(find $ROOT/gpurun_out/${TAG}_exact -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/$TAG/exact_kernel_stats.csv
+cd $ROOT
+python tests/tools/gpu_exact_campaign.py 8 > gpurun_out/$TAG/exact_campaign.log 2>&1
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact --no-general-path --no-pipelined > gpurun_out/$TAG/bench_line_steps20_warmup5.json 2>> gpurun_out/$TAG/bench.err
