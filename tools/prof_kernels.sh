@@ -9,7 +9,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ "${MN_PROF_BENCH:-1}" = "1" ]; then
   # the bench's own timed loop (4 images in rotation, launch of step i+1 before the read-back of step i)
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 "$ROOT/bench.py" --steps "$NIMG" --warmup 4 --no-cpu-baseline --no-general-path --no-pipelined --spin-seconds 0 ${MN_PROF_ARGS:-} > "$OUT/stdout.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 "$ROOT/bench.py" --steps "$NIMG" --warmup 4 --no-cpu-baseline --no-general-path --no-pipelined --no-exact --spin-seconds 0 ${MN_PROF_ARGS:-} > "$OUT/stdout.log" 2>&1
   NIMG=$((NIMG + 4 + 1 + 4))     # + warm-up, the initialisation call and the four id-match images
 else
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 "$ROOT/tools/prof_components.py" "$NIMG" > "$OUT/stdout.log" 2>&1
