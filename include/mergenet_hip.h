@@ -203,6 +203,18 @@ int mn_segment_launch(mn_context* ctx, const float* d_class_pred, int class_dim,
                       int* d_partition, const mn_options* opts, void* stream);
 int mn_segment_finish(mn_context* ctx, mn_stats* stats);
 
+/* `count` images of ONE shape through the exact engine (MN_MODE_EXACT) together: the engine's loop is one
+ * wavefront per image, so a batch is ONE launch with a workgroup per image -- images in flight are how the
+ * sequential order gets throughput (the reference scales the same way, by processes: --num-jobs).  One
+ * context per image (each holds its image's workspace, ~1.5 GB at 512x1024, ~6 GB at 1024x2048); arrays of
+ * `count` device pointers (host arrays); d_partition may be NULL; stats: `count` entries or NULL.  The call
+ * returns when all images are done.  Results are those of `count` separate MN_MODE_EXACT calls. */
+int mn_segment_exact_batch(mn_context** ctxs, int count, const float* const* d_class_pred, int class_dim,
+                           const float* const* d_adj_pred, int offset_dim, int img_width, int img_height,
+                           int num_classes, const int* offset_list, int* const* d_mask,
+                           int* const* d_object_class, int* const* d_partition, const mn_options* opts,
+                           void* stream, mn_stats* stats);
+
 /* Phase A alone (per-pixel class log-probs + argmax, per-edge log-odds and initial priorities,
  * best initial record per pixel).  Used by bench.py / profiles to time the affinity-scoring pass
  * against the HBM roofline, and by tests to compare phase-A arrays with the oracle.

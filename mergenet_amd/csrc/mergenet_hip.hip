@@ -145,6 +145,10 @@ struct mn_context {
     size_t bytes;
     XCtl* h_ctl;                  // pinned
     int lds_ready;
+    int prerun;                   // set-up and loop of the image have run (as part of a batch)
+    ImgParams* d_P;               // device copies of a batch's parameters (first context of the batch)
+    XState* d_X;
+    int batch_cap;
   } xw;
   // staging for the host-pointer entry points
   float *d_class, *d_same;
@@ -174,7 +178,9 @@ static void x_free(mn_context* c) {
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
   c->bytes -= c->xw.bytes;
+  ImgParams* keepP = c->xw.d_P; XState* keepX = c->xw.d_X; const int keepcap = c->xw.batch_cap;
   memset(&c->xw, 0, sizeof(c->xw));
+  c->xw.d_P = keepP; c->xw.d_X = keepX; c->xw.batch_cap = keepcap;
 }
 
 template <typename T>
@@ -417,6 +423,8 @@ extern "C" void mn_destroy(mn_context* c) {
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   x_free(c);
+  if (c->xw.d_P) (void)hipFree(c->xw.d_P);
+  if (c->xw.d_X) (void)hipFree(c->xw.d_X);
   free_records(c);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   if (c->h_touch) (void)hipHostFree(c->h_touch);
@@ -976,48 +984,95 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   return MN_OK;
 }
 
-static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
-  int rc = exact_setup(c, P, st);
-  if (rc != MN_OK) return rc;
-  mn_context::XWork& w = c->xw;
-  XState& X = w.X;
-  const size_t N = (size_t)P.N;
-  const size_t lds = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + 64;
-  if (!w.lds_ready) {
+// The loop for a batch of images (contexts set up by exact_setup), ONE launch with a workgroup per image;
+// device copies of the images' parameters live in the first context.
+static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st) {
+  mn_context::XWork& w0 = cs[0]->xw;
+  if (w0.batch_cap < n) {
+    if (w0.d_P) (void)hipFree(w0.d_P);
+    if (w0.d_X) (void)hipFree(w0.d_X);
+    w0.d_P = nullptr; w0.d_X = nullptr;
+    MN_HIP(hipMalloc(reinterpret_cast<void**>(&w0.d_P), (size_t)n * sizeof(ImgParams)));
+    MN_HIP(hipMalloc(reinterpret_cast<void**>(&w0.d_X), (size_t)n * sizeof(XState)));
+    w0.batch_cap = n;
+  }
+  size_t lds = 0;
+  long long max_total = 0;
+  {
+    XState* hx = static_cast<XState*>(malloc((size_t)n * sizeof(XState)));
+    if (!hx) return MN_ERR_INTERNAL;
+    for (int i = 0; i < n; i++) {
+      const XState& X = cs[i]->xw.X;
+      hx[i] = X;
+      const size_t l = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + 64;
+      if (l > lds) lds = l;
+      // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per
+      // record (plus slack) is the hard stop of a run, whatever the input
+      const long long mt = 8LL * (long long)X.NL + 65536;
+      if (mt > max_total) max_total = mt;
+    }
+    hipError_t e1 = hipMemcpyAsync(w0.d_P, Ps, (size_t)n * sizeof(ImgParams), hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipMemcpyAsync(w0.d_X, hx, (size_t)n * sizeof(XState), hipMemcpyHostToDevice, st);
+    hipError_t e3 = hipStreamSynchronize(st);
+    free(hx);
+    MN_HIP(e1); MN_HIP(e2); MN_HIP(e3);
+  }
+  if (!w0.lds_ready) {
     MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
-    w.lds_ready = 1;
+    w0.lds_ready = 1;
   }
-  // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per record
-  // (plus slack) is the hard stop of a run, whatever the input
-  const long long max_total = 8LL * (long long)X.NL + 65536;
   long long per_launch = 1LL << 24;                  // steps per launch (MN_X_BUDGET: tests of the relaunch)
   if (const char* e = getenv("MN_X_BUDGET")) { const long long v = atoll(e); if (v > 0) per_launch = v; }
   const long long max_launches = 1 << 20;
   for (long long it = 0; it < max_launches; it++) {
-    const long long left = max_total - w.h_ctl->steps;
+    long long most = 0;
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+      mn_context::XWork& w = cs[i]->xw;
+      if (it > 0 && w.h_ctl->status == MN_X_DONE) continue;
+      any = true;
+      if (w.h_ctl->steps > most) most = w.h_ctl->steps;
+      hipLaunchKernelGGL(mn_x_build_l1, dim3(w.X.NB), dim3(64), 0, st, w.X);
+    }
+    if (!any) break;
+    const long long left = max_total - most;
     if (left <= 0) {
       fprintf(stderr, "mergenet_hip: exact engine exceeded %lld steps\n", max_total);
       return MN_ERR_INTERNAL;
     }
     const long long budget = left < per_launch ? left : per_launch;
-    hipLaunchKernelGGL(mn_x_build_l1, dim3(X.NB), dim3(64), 0, st, X);
-    hipLaunchKernelGGL(mn_x_run, dim3(1), dim3(64), lds, st, P, X, budget);
+    hipLaunchKernelGGL(mn_x_run, dim3((unsigned)n), dim3(64), lds, st, (const ImgParams*)w0.d_P, (const XState*)w0.d_X, budget);
     MN_HIP(hipGetLastError());
-    MN_HIP(hipMemcpyAsync(w.h_ctl, X.ctl, sizeof(XCtl), hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < n; i++)
+      MN_HIP(hipMemcpyAsync(cs[i]->xw.h_ctl, cs[i]->xw.X.ctl, sizeof(XCtl), hipMemcpyDeviceToHost, st));
     MN_HIP(hipStreamSynchronize(st));
-    const int status = w.h_ctl->status;
-    if (status == MN_X_DONE) break;
-    if (status == MN_X_BUDGET) continue;
-    if (status == MN_X_ARENA_FULL || status == MN_X_HASH_FULL) {
-      fprintf(stderr, "mergenet_hip: exact engine out of %s after %lld steps\n",
-              status == MN_X_ARENA_FULL ? "adjacency arena" : "pair table", w.h_ctl->steps);
-      return MN_ERR_CAPACITY;
+    bool all_done = true;
+    for (int i = 0; i < n; i++) {
+      const int status = cs[i]->xw.h_ctl->status;
+      if (status == MN_X_DONE) continue;
+      all_done = false;
+      if (status == MN_X_BUDGET) continue;
+      if (status == MN_X_ARENA_FULL || status == MN_X_HASH_FULL) {
+        fprintf(stderr, "mergenet_hip: exact engine out of %s after %lld steps (image %d of the batch)\n",
+                status == MN_X_ARENA_FULL ? "adjacency arena" : "pair table", cs[i]->xw.h_ctl->steps, i);
+        return MN_ERR_CAPACITY;
+      }
+      fprintf(stderr, "mergenet_hip: exact engine stopped with status %d after %lld steps\n", status, cs[i]->xw.h_ctl->steps);
+      return MN_ERR_INTERNAL;
     }
-    fprintf(stderr, "mergenet_hip: exact engine stopped with status %d after %lld steps\n", status, w.h_ctl->steps);
-    return MN_ERR_INTERNAL;
+    if (all_done) break;
   }
-  if (w.h_ctl->status != MN_X_DONE) return MN_ERR_INTERNAL;
+  for (int i = 0; i < n; i++)
+    if (cs[i]->xw.h_ctl->status != MN_X_DONE) return MN_ERR_INTERNAL;
+  return MN_OK;
+}
+
+// what the output stage reads: sizes, classes and class sums of the survivors, step counters
+static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
+  mn_context::XWork& w = c->xw;
+  XState& X = w.X;
+  const size_t N = (size_t)P.N;
   if (getenv("MN_TRACE_EXACT"))
     fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld slow inserts %lld set-up overflow %d arena %llu of %llu\n",
             w.h_ctl->steps, w.h_ctl->merges, w.h_ctl->rescans, w.h_ctl->reallocs, w.h_ctl->folded,
@@ -1042,7 +1097,6 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
       free(h);
     }
   }
-  // what the output stage reads: class sums of the survivors (plane-major), step counters
   hipLaunchKernelGGL(mn_x_export_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->osize, c->ocls,
                      c->lpsum, c->lpvalid);
   const long long steps = w.h_ctl->steps, merges = w.h_ctl->merges;
@@ -1055,6 +1109,23 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   MN_HIP(hipMemcpyAsync(c->cnt, c->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, st));
   MN_HIP(hipGetLastError());
   return MN_OK;
+}
+
+// set-up, loop and hand-over of ONE image; in a batch (mn_segment_exact_batch) set-up and loop have run for
+// all images together and only the hand-over is left (xw.prerun)
+static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
+  int rc = MN_OK;
+  if (!c->xw.prerun) {
+    rc = exact_setup(c, P, st);
+    if (rc != MN_OK) return rc;
+    mn_context* one[1] = {c};
+    rc = exact_loop(one, 1, &P, st);
+    if (rc != MN_OK) return rc;
+  } else {
+    MN_HIP(hipEventRecord(c->ev[1], st));
+    MN_HIP(hipEventRecord(c->ev[2], st));
+  }
+  return exact_export(c, P, st);
 }
 
 // Internal verdicts of a speculative attempt (never returned to the caller).
@@ -1179,7 +1250,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     mode = MN_MODE_ROUNDS;
   // the sequential order at any size: the exact engine (debug_flags bit 8 keeps the small-list finisher
   // with its O(R) arg-max per step, for comparison)
-  const bool xengine = mode == MN_MODE_EXACT && !(opts->debug_flags & 256);
+  const bool xengine = mode == MN_MODE_EXACT && (!(opts->debug_flags & 256) || c->xw.prerun);
   ObjState S = obj_state(c);
   // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
   // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph
@@ -1694,6 +1765,54 @@ extern "C" int mn_segment_device(mn_context* c, const float* d_class_pred, int c
     return rc;
   }
   return mn_segment_finish(c, stats);
+}
+
+// A batch of images of one shape through the exact engine in ONE launch of its loop (a workgroup per image);
+// see include/mergenet_hip.h.
+extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float* const* d_class_pred, int class_dim,
+                                      const float* const* d_adj_pred, int offset_dim, int W, int H, int num_classes,
+                                      const int* offset_list, int* const* d_mask, int* const* d_object_class,
+                                      int* const* d_partition, const mn_options* opts, void* stream,
+                                      mn_stats* stats) {
+  mn_options o;
+  if (opts) o = *opts; else mn_default_options(&o);
+  o.mode = MN_MODE_EXACT;
+  if (!ctxs || count <= 0 || count > 4096 || !d_class_pred || !d_adj_pred || !d_mask || !d_object_class) {
+    g_last_status = MN_ERR_ARGUMENT;
+    return MN_ERR_ARGUMENT;
+  }
+  for (int i = 0; i < count; i++) {
+    if (!ctxs[i] || ctxs[i]->pend.active || ctxs[i]->device != ctxs[0]->device) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+    for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+    const int rc = check_args(ctxs[i], class_dim, offset_dim, W, H, num_classes, offset_list, &o);
+    if (rc != MN_OK || !d_class_pred[i] || !d_adj_pred[i] || !d_mask[i] || !d_object_class[i]) {
+      g_last_status = rc != MN_OK ? rc : MN_ERR_ARGUMENT;
+      return g_last_status;
+    }
+  }
+  MN_HIP(hipSetDevice(ctxs[0]->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ImgParams* Ps = static_cast<ImgParams*>(malloc((size_t)count * sizeof(ImgParams)));
+  if (!Ps) return MN_ERR_INTERNAL;
+  int rc = MN_OK;
+  for (int i = 0; i < count && rc == MN_OK; i++) {
+    fill_params(&Ps[i], d_class_pred[i], d_adj_pred[i], offset_dim, W, H, num_classes, offset_list, &o);
+    rc = exact_setup(ctxs[i], Ps[i], st);
+  }
+  if (rc == MN_OK) rc = exact_loop(ctxs, count, Ps, st);
+  free(Ps);
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  // hand-over and output stage of every image (labels, mask, class table, certificate, log-likelihood)
+  for (int i = 0; i < count; i++) {
+    ctxs[i]->xw.prerun = 1;
+    const int r = segment_attempt(ctxs[i], d_class_pred[i], class_dim, d_adj_pred[i], offset_dim, W, H, num_classes,
+                                  offset_list, d_mask[i], d_object_class[i], d_partition ? d_partition[i] : nullptr,
+                                  &o, stream, stats ? &stats[i] : nullptr, MN_MODE_EXACT, false);
+    ctxs[i]->xw.prerun = 0;
+    if (r != MN_OK && rc == MN_OK) rc = r;
+  }
+  g_last_status = rc;
+  return rc;
 }
 
 extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int class_dim,

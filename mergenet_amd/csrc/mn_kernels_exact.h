@@ -417,7 +417,13 @@ __device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int 
   if (lane == 0) l2[g] = v;
 }
 
-__global__ __launch_bounds__(64) void mn_x_run(ImgParams P, XState X, long long budget) {
+// One workgroup (= one wavefront) per image: block b runs the loop of image b of a batch (images are
+// independent; the reference scales the same way, by processes).
+__global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps, const XState* __restrict__ Xs,
+                                               long long budget) {
+  const ImgParams& P = Ps[blockIdx.x];
+  const XState X = Xs[blockIdx.x];
+  if (X.ctl->status == MN_X_DONE) return;           // (a relaunch of the batch: this image has finished)
   extern __shared__ __attribute__((aligned(16))) unsigned char x_smem[];
   u64* l1 = reinterpret_cast<u64*>(x_smem);                        // [NBpad]
   u64* l2 = l1 + X.NBpad;                                          // [NG]

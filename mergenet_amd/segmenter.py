@@ -77,7 +77,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
-           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_segment_host", "c_run_segmentation",
+           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_segment_exact_batch", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
            "mn_unpack_runs_batch_device",
@@ -118,6 +118,11 @@ def load_library() -> ctypes.CDLL:
     lib.mn_segment_launch.restype = ctypes.c_int
     lib.mn_segment_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(MnStats)]
     lib.mn_segment_finish.restype = ctypes.c_int
+    _vpp = ctypes.POINTER(ctypes.c_void_p)
+    lib.mn_segment_exact_batch.argtypes = [_vpp, ctypes.c_int, _vpp, ctypes.c_int, _vpp, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _i32p, _vpp, _vpp, _vpp,
+                                           ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.POINTER(MnStats)]
+    lib.mn_segment_exact_batch.restype = ctypes.c_int
     lib.mn_score_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                     ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
@@ -674,6 +679,56 @@ class PendingSegment:
                 raise MergeNetError(rc)
             self._done = self._out + (stats.as_dict(),)
         return self._done
+
+
+class ExactBatch:
+    """``count`` images of one shape through the exact engine in ONE launch of its loop
+    (``mn_segment_exact_batch``): the engine is one wavefront per image, so images in flight are its
+    throughput.  One context (workspace) per image; ``segment`` takes lists of [C,H,W] / [O,H,W] tensors
+    (at most ``count``) and returns a list of what :meth:`Merger.segment` returns."""
+
+    def __init__(self, H: int, W: int, C: int, O: int, count: int, device: Optional[int] = None):
+        if count < 1:
+            raise ValueError("count >= 1")
+        self.mergers = [Merger(H, W, C, O, device=device) for _ in range(count)]
+        self.lib = self.mergers[0].lib
+        self.torch = self.mergers[0].torch
+
+    def segment(self, class_probs: Sequence, same_probs: Sequence, offsets, opts: Optional[MnOptions] = None,
+                want_partition: bool = False):
+        torch = self.torch
+        n = len(class_probs)
+        if n < 1 or n > len(self.mergers) or len(same_probs) != n:
+            raise ValueError("between 1 and %d images" % len(self.mergers))
+        shape = None
+        for cp, sp in zip(class_probs, same_probs):
+            C, H, W, O, off = self.mergers[0]._check(cp, sp, offsets)
+            if shape is not None and shape != (C, H, W, O):
+                raise ValueError("the images of a batch have one shape")
+            shape = (C, H, W, O)
+        opts = opts if opts is not None else default_options()
+        dev = class_probs[0].device
+        masks = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(n)]
+        tables = [torch.empty((H * W,), dtype=torch.int32, device=dev) for _ in range(n)]
+        parts = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(n)] if want_partition else None
+        vp = ctypes.c_void_p * n
+        stats = (MnStats * n)()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.mn_segment_exact_batch(
+            vp(*[m.handle for m in self.mergers[:n]]), n, vp(*[t.data_ptr() for t in class_probs]), C,
+            vp(*[t.data_ptr() for t in same_probs]), O, W, H, C, off.ctypes.data_as(_i32p),
+            vp(*[t.data_ptr() for t in masks]), vp(*[t.data_ptr() for t in tables]),
+            vp(*[t.data_ptr() for t in parts]) if parts is not None else None,
+            ctypes.byref(opts), ctypes.c_void_p(stream), stats)
+        if rc != 0:
+            raise MergeNetError(rc)
+        return [(masks[i], tables[i], parts[i] if parts is not None else None, stats[i].as_dict())
+                for i in range(n)]
+
+    def close(self):
+        for m in self.mergers:
+            m.close()
+        self.mergers = []
 
 
 class MergerPool:

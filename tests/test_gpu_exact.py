@@ -203,3 +203,41 @@ def test_unproven_fast_path_is_opt_in_and_says_so(oracle):
     mask, classes, part, st = _run(g, seg.MN_MODE_ROUNDS, require_proof=seg.MN_PROVE_ALWAYS)
     assert st["proof"] == seg.MN_PROOF_SEQUENTIAL and st["mode_used"] == seg.MN_MODE_EXACT
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_a_batch_in_one_launch_equals_the_single_calls(oracle):
+    """mn_segment_exact_batch: several images, a workgroup each, in ONE launch of the loop (and relaunched on a
+    small step budget while some images have already finished): the reference's mask and classes for each."""
+    import torch
+    gs = [gu.load(n) for n in ("cseg_crowd48_256x512_s6400", "cseg_blur_256x512_r2", "cseg_synth_256x512",
+                               "cseg_crowd48_256x512_s6408")]
+    g0 = gs[0]
+    H, W, C = g0["spec"]["H"], g0["spec"]["W"], g0["spec"]["C"]
+    for g in gs:
+        assert (g["spec"]["H"], g["spec"]["W"], g["spec"]["C"], g["spec"]["opts"]) == (H, W, C, g0["spec"]["opts"])
+        assert np.array_equal(np.asarray(g["offsets"]), np.asarray(g0["offsets"]))
+    sdb, omf, bias = g0["spec"]["opts"]
+    o = seg.default_options(same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias,
+                            mode=seg.MN_MODE_EXACT, clip_inputs=1)
+    cps = [torch.from_numpy(np.ascontiguousarray(g["class_probs"], dtype=np.float32)).cuda() for g in gs]
+    sps = [torch.from_numpy(np.ascontiguousarray(g["sameness_probs"], dtype=np.float32)).cuda() for g in gs]
+    batch = seg.ExactBatch(H, W, C, len(g0["offsets"]), len(gs))
+    old = os.environ.get("MN_X_BUDGET")
+    try:
+        for budget in (None, "40000"):
+            if budget:
+                os.environ["MN_X_BUDGET"] = budget
+            res = batch.segment(cps, sps, g0["offsets"], o, want_partition=True)
+            for g, (mask, table, part, st) in zip(gs, res):
+                assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] >= 1
+                assert st["merges"] == H * W - st["num_objects"]
+                assert oracle.masks_equivalent(mask.cpu().numpy(), seg._class_list(table.cpu().numpy()),
+                                               g["mask"], g["object_class"]), st
+        with pytest.raises(ValueError):
+            batch.segment(cps + cps, sps + sps, g0["offsets"], o)
+    finally:
+        if old is None:
+            os.environ.pop("MN_X_BUDGET", None)
+        else:
+            os.environ["MN_X_BUDGET"] = old
+        batch.close()
