@@ -157,7 +157,13 @@ typedef struct mn_stats {
                                   record id, which agrees with the reference on every vector held)   */
   int cores_condemned;         /* general rounds: 1 if a core held an edge that was not positive and
                                   fell apart again (mn_core_check); 0 otherwise                    */
-  int reserved_i[2];
+  int tied_steps;              /* MN_MODE_EXACT: pops at which a second live record held the bit-equal stored
+                                  priority (saturates at INT_MAX).  0 = every pop was forced: the result is
+                                  the reference's whatever its heap does among equals.  > 0: the reference's
+                                  std::priority_queue picks by heap position, the engine by lowest record id;
+                                  the two orders usually commute, DESIGN.md section 5 has the inputs where
+                                  they do not (radius-4 blurred, clipped maps)                             */
+  int tied_merges;             /* ... of which were merges */
 } mn_stats;
 
 typedef struct mn_context mn_context;

@@ -149,6 +149,8 @@ struct mn_context {
     ImgParams* d_P;               // device copies of a batch's parameters (first context of the batch)
     XState* d_X;
     int batch_cap;
+    int arena_extra;              // arena words per pixel beyond the initial arrays (doubled when a run fills it)
+    int table_shift;              // pair table: buckets = next_pow2(records >> table_shift)
   } xw;
   // staging for the host-pointer entry points
   float *d_class, *d_same;
@@ -178,9 +180,10 @@ static void x_free(mn_context* c) {
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
   c->bytes -= c->xw.bytes;
-  ImgParams* keepP = c->xw.d_P; XState* keepX = c->xw.d_X; const int keepcap = c->xw.batch_cap;
+  const mn_context::XWork keep = c->xw;
   memset(&c->xw, 0, sizeof(c->xw));
-  c->xw.d_P = keepP; c->xw.d_X = keepX; c->xw.batch_cap = keepcap;
+  c->xw.d_P = keep.d_P; c->xw.d_X = keep.d_X; c->xw.batch_cap = keep.batch_cap;
+  c->xw.arena_extra = keep.arena_extra; c->xw.table_shift = keep.table_shift;
 }
 
 template <typename T>
@@ -192,8 +195,10 @@ static hipError_t x_alloc(mn_context* c, T** p, size_t n) {
 }
 
 // Sizes the workspace for an image of N pixels, O offsets, C classes.  Per pixel (C = 9, O = 10):
-// records 20 B x O, pair table 64-128 B x O, class vectors 4 B x C, objects 20 B, adjacency arena
-// 4 B x 384: ~3 KB, 6 GB for 1024 x 2048 (of 288 GB).
+// records 20 B x O, pair table 32-64 B x O (load <= 0.5 at the start, falling: pairs only disappear), class
+// vectors 4 B x C, objects 20 B, adjacency arena 4 B x (64 + 192) (152 words per pixel are used at 512x1024;
+// a run that fills the arena or the table is repeated with twice as much: exact_run): ~1.7 KB, 3.6 GB for
+// 1024 x 2048 (of 288 GB) -- the workspace bounds the images in flight (mn_segment_exact_batch).
 static int x_ensure(mn_context* c, int N, int O, int C) {
   mn_context::XWork& w = c->xw;
   const size_t NL = (size_t)N * O;
@@ -202,11 +207,16 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   while ((NL + B - 1) / B > MN_X_MAXBLOCKS) B <<= 1;
   const size_t NB = (NL + B - 1) / B;
   const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
-  const size_t nbuckets = next_pow2(NL + 256);       // 4 slots each: load <= 0.25
+  if (w.arena_extra <= 0) {
+    w.arena_extra = 192;
+    if (const char* e = getenv("MN_X_ARENA_EXTRA")) { const int v = atoi(e); if (v > 0) w.arena_extra = v; }   // (tests)
+    w.table_shift = 1;
+  }
+  const size_t nbuckets = next_pow2(((NL + 256) >> w.table_shift) + 1);   // 4 slots each
   if (nbuckets * 4 >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   int cap0 = 64;
   while (cap0 < 4 * O) cap0 <<= 1;
-  const size_t arena_cap = (size_t)N * cap0 + (size_t)N * 320 + 65536;
+  const size_t arena_cap = (size_t)N * cap0 + (size_t)N * (size_t)w.arena_extra + 65536;
   if (arena_cap >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   const size_t ovf_cap = NL / 256 + 4096;
   if (w.n_pix < (size_t)N || w.n_rec < NL || w.n_cls_floats < (size_t)N * C || w.hcap < nbuckets ||
@@ -985,8 +995,9 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
 }
 
 // The loop for a batch of images (contexts set up by exact_setup), ONE launch with a workgroup per image;
-// device copies of the images' parameters live in the first context.
-static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st) {
+// device copies of the images' parameters live in the first context given.  `full[i]` is set for an image that ran
+// out of arena or pair table (its workspace grows and exact_run repeats it; the others finish).
+static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st, unsigned char* full) {
   mn_context::XWork& w0 = cs[0]->xw;
   if (w0.batch_cap < n) {
     if (w0.d_P) (void)hipFree(w0.d_P);
@@ -1030,7 +1041,7 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
     bool any = false;
     for (int i = 0; i < n; i++) {
       mn_context::XWork& w = cs[i]->xw;
-      if (it > 0 && w.h_ctl->status == MN_X_DONE) continue;
+      if (it > 0 && w.h_ctl->status != MN_X_BUDGET) continue;
       any = true;
       if (w.h_ctl->steps > most) most = w.h_ctl->steps;
       hipLaunchKernelGGL(mn_x_build_l1, dim3(w.X.NB), dim3(64), 0, st, w.X);
@@ -1054,9 +1065,11 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
       all_done = false;
       if (status == MN_X_BUDGET) continue;
       if (status == MN_X_ARENA_FULL || status == MN_X_HASH_FULL) {
-        fprintf(stderr, "mergenet_hip: exact engine out of %s after %lld steps (image %d of the batch)\n",
-                status == MN_X_ARENA_FULL ? "adjacency arena" : "pair table", cs[i]->xw.h_ctl->steps, i);
-        return MN_ERR_CAPACITY;
+        if (getenv("MN_TRACE_EXACT"))
+          fprintf(stderr, "exact engine: out of %s after %lld steps (image %d of the batch): workspace grows, run repeated\n",
+                  status == MN_X_ARENA_FULL ? "adjacency arena" : "pair table", cs[i]->xw.h_ctl->steps, i);
+        full[i] = (unsigned char)status;
+        continue;
       }
       fprintf(stderr, "mergenet_hip: exact engine stopped with status %d after %lld steps\n", status, cs[i]->xw.h_ctl->steps);
       return MN_ERR_INTERNAL;
@@ -1064,8 +1077,38 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
     if (all_done) break;
   }
   for (int i = 0; i < n; i++)
-    if (cs[i]->xw.h_ctl->status != MN_X_DONE) return MN_ERR_INTERNAL;
+    if (cs[i]->xw.h_ctl->status != MN_X_DONE && !full[i]) return MN_ERR_INTERNAL;
   return MN_OK;
+}
+
+// Set-up and loop of a batch; an image whose workspace was too small is repeated with a larger one.
+static int exact_run(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st) {
+  mn_context** sub = static_cast<mn_context**>(malloc((size_t)n * sizeof(mn_context*)));
+  ImgParams* subP = static_cast<ImgParams*>(malloc((size_t)n * sizeof(ImgParams)));
+  unsigned char* full = static_cast<unsigned char*>(malloc((size_t)n));
+  int rc = (sub && subP && full) ? MN_OK : MN_ERR_INTERNAL;
+  int m = n;
+  for (int i = 0; i < n && rc == MN_OK; i++) { sub[i] = cs[i]; subP[i] = Ps[i]; }
+  for (int attempt = 0; rc == MN_OK && m > 0; attempt++) {
+    if (attempt == 8) { rc = MN_ERR_CAPACITY; break; }
+    for (int i = 0; i < m && rc == MN_OK; i++) rc = exact_setup(sub[i], subP[i], st);
+    if (rc != MN_OK) break;
+    memset(full, 0, (size_t)m);
+    rc = exact_loop(sub, m, subP, st, full);
+    if (rc != MN_OK) break;
+    int k = 0;
+    for (int i = 0; i < m; i++) {
+      if (!full[i]) continue;
+      mn_context::XWork& w = sub[i]->xw;
+      if (full[i] == MN_X_ARENA_FULL) w.arena_extra *= 2;
+      else if (w.table_shift > 0) w.table_shift--;
+      else { rc = MN_ERR_CAPACITY; break; }
+      sub[k] = sub[i]; subP[k] = subP[i]; k++;
+    }
+    m = k;
+  }
+  free(sub); free(subP); free(full);
+  return rc;
 }
 
 // what the output stage reads: sizes, classes and class sums of the survivors, step counters
@@ -1116,10 +1159,8 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
 static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   int rc = MN_OK;
   if (!c->xw.prerun) {
-    rc = exact_setup(c, P, st);
-    if (rc != MN_OK) return rc;
     mn_context* one[1] = {c};
-    rc = exact_loop(one, 1, &P, st);
+    rc = exact_run(one, 1, &P, st);
     if (rc != MN_OK) return rc;
   } else {
     MN_HIP(hipEventRecord(c->ev[1], st));
@@ -1167,6 +1208,12 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->rounds = rounds;
     stats->cores_condemned = c->cores_used ? (c->h_scalars[9] != 0) : 0;
     stats->finisher_steps = c->h_cnt->finisher_steps;
+    stats->tied_steps = stats->tied_merges = 0;
+    if (mode == MN_MODE_EXACT && c->xw.h_ctl && (!(opts->debug_flags & 256) || c->xw.prerun)) {
+      const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
+      stats->tied_steps = (int)(ts > 0x7FFFFFFF ? 0x7FFFFFFF : ts);
+      stats->tied_merges = (int)(tm > 0x7FFFFFFF ? 0x7FFFFFFF : tm);
+    }
     stats->initial_records = R0;
     stats->merges = merges;
     stats->total_logprob = want_cert ? c->h_lp[0] : NAN;
@@ -1795,11 +1842,9 @@ extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float*
   ImgParams* Ps = static_cast<ImgParams*>(malloc((size_t)count * sizeof(ImgParams)));
   if (!Ps) return MN_ERR_INTERNAL;
   int rc = MN_OK;
-  for (int i = 0; i < count && rc == MN_OK; i++) {
+  for (int i = 0; i < count; i++)
     fill_params(&Ps[i], d_class_pred[i], d_adj_pred[i], offset_dim, W, H, num_classes, offset_list, &o);
-    rc = exact_setup(ctxs[i], Ps[i], st);
-  }
-  if (rc == MN_OK) rc = exact_loop(ctxs, count, Ps, st);
+  rc = exact_run(ctxs, count, Ps, st);
   free(Ps);
   if (rc != MN_OK) { g_last_status = rc; return rc; }
   // hand-over and output stage of every image (labels, mask, class table, certificate, log-likelihood)

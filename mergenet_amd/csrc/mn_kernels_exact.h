@@ -48,6 +48,8 @@ struct XCtl {
   long long steps, merges, rescans, reallocs, folded, adopted, slow_inserts;
   unsigned long long bump;    // next free arena entry
   long long stamps[16];       // -DMN_X_STAMPS (diagnostic build): cycles per phase of the loop
+  long long tied_steps;       // pops at which a second live record held the bit-equal stored priority
+  long long tied_merges;      // ... of which merged
 };
 
 // one record (AdjacencyRecord, segment.h:175-232): ONE 16-byte load
@@ -423,7 +425,11 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
                                                long long budget) {
   const ImgParams& P = Ps[blockIdx.x];
   const XState X = Xs[blockIdx.x];
-  if (X.ctl->status == MN_X_DONE) return;           // (a relaunch of the batch: this image has finished)
+  {
+    // (a relaunch of the batch: this image has finished, or waits for a larger workspace)
+    const int st0 = X.ctl->status;
+    if (st0 != MN_X_RUNNING && st0 != MN_X_BUDGET) return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char x_smem[];
   u64* l1 = reinterpret_cast<u64*>(x_smem);                        // [NBpad]
   u64* l2 = l1 + X.NBpad;                                          // [NG]
@@ -441,6 +447,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   MN_X_LDS_SYNC();
 
   long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0, slow_inserts = 0;
+  long long tied_steps = 0, tied_merges = 0;
   unsigned long long bump = X.ctl->bump;
   int status = X.ctl->status < 0 || X.ctl->status == MN_X_HASH_FULL ? X.ctl->status : MN_X_RUNNING;
 #ifdef MN_X_STAMPS
@@ -461,6 +468,17 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     if (steps >= budget) { status = MN_X_BUDGET; break; }
     const unsigned rid = mn_x_rid(top);
     const unsigned blk = rid >> X.Blog;
+    // Is the pop forced?  A second live record with the bit-equal stored priority (in another group of
+    // blocks, another block of this group, or -- below -- this block) means the reference's heap decides
+    // between them (segment.h:270-275 compares the float only); the engine takes the lowest record id.
+    int eqg = 0;
+    for (int g = lane; g < X.NG; g += 64) eqg += ((unsigned)(l2[g] >> 32) == gword) ? 1 : 0;
+    const u64 tg = __ballot(eqg > 0);
+    bool tied = (tg & (tg - 1ull)) != 0ull || __ballot(eqg > 1) != 0ull;
+    {
+      const u64 tb = __ballot((unsigned)(l1[(blk & ~63u) + lane] >> 32) == gword);
+      tied = tied || (tb & (tb - 1ull)) != 0ull;
+    }
     MN_X_STAMP(1);
     // the record, and beside it the popped block without it (its maximum changes either way)
     uint4 rraw;
@@ -469,6 +487,8 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     const float S = __uint_as_float(rraw.z);
     const unsigned slot_r = rraw.w;
     if (key == MN_EMPTY) { status = MN_ERR_INTERNAL; break; }
+    tied = tied || (unsigned)(bm >> 32) == gword;
+    tied_steps += tied ? 1 : 0;
     MN_X_STAMP(2);
     const int x = mn_key_u(key), y = mn_key_v(key);
     // ---- re-score (segment.cc:560): both objects' state in one round trip ----
@@ -548,6 +568,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       }
     }
     merges++;
+    tied_merges += tied ? 1 : 0;
     // object state of the survivor (:635-642); the absorbed object only keeps its parent link
     if (lane < C) { const float s0 = ax0 + ay0; X.lp[(size_t)a * C + lane] = s0; sh_lpa[lane] = s0; }
     if (lane + 64 < C) { const float s1 = ax1 + ay1; X.lp[(size_t)a * C + lane + 64] = s1; sh_lpa[lane + 64] = s1; }
@@ -778,6 +799,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     c->status = status;
     c->steps += steps; c->merges += merges; c->rescans += rescans; c->reallocs += reallocs;
     c->folded += folded; c->adopted += adopted; c->slow_inserts += slow_inserts;
+    c->tied_steps += tied_steps; c->tied_merges += tied_merges;
     c->bump = bump;
   }
 }

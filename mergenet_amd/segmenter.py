@@ -66,10 +66,10 @@ class MnStats(ctypes.Structure):
                 ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
                 ("ms_cc_edges", ctypes.c_float), ("ms_cc_cross", ctypes.c_float),
-                ("proof", ctypes.c_int), ("cores_condemned", ctypes.c_int), ("reserved_i", ctypes.c_int * 2)]
+                ("proof", ctypes.c_int), ("cores_condemned", ctypes.c_int), ("tied_steps", ctypes.c_int), ("tied_merges", ctypes.c_int)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 _f32p = ctypes.POINTER(ctypes.c_float)

@@ -241,3 +241,26 @@ def test_a_batch_in_one_launch_equals_the_single_calls(oracle):
         else:
             os.environ["MN_X_BUDGET"] = old
         batch.close()
+
+
+def test_a_full_workspace_grows_and_the_run_is_repeated(oracle, monkeypatch, capfd):
+    """The adjacency arena is sized for what images use (with slack); a run that fills it stops with a
+    consistent state, the workspace doubles and the image is run again -- same result."""
+    monkeypatch.setenv("MN_X_ARENA_EXTRA", "20")
+    monkeypatch.setenv("MN_TRACE_EXACT", "1")
+    g = gu.load("cseg_crowd48_256x512_s6400")
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    assert "workspace grows" in capfd.readouterr().err
+    assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] >= 1
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_tied_pops_are_counted():
+    """stats.tied_steps: pops at which a second live record held the bit-equal stored priority.  Continuous
+    (unclipped, network-like) values give none or a handful; the clipped generator's plateaus give thousands."""
+    adv = _run(gu.load("cseg_adv_64x64_o0"), seg.MN_MODE_EXACT)[3]
+    assert adv["tied_steps"] <= 4 and adv["tied_merges"] <= adv["tied_steps"]
+    syn = _run(gu.load("cseg_synth_64x128_n60"), seg.MN_MODE_EXACT)[3]
+    assert syn["tied_steps"] > 1000 and 0 < syn["tied_merges"] <= syn["tied_steps"]
+    fast = _run(gu.load("cseg_synth_64x128_n15"), seg.MN_MODE_COMPONENTS, require_proof=-1)[3]
+    assert fast["tied_steps"] == 0 and fast["tied_merges"] == 0

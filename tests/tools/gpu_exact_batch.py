@@ -26,6 +26,7 @@ def main():
     ref = [one.segment(cps[i], sps[i], offs, o) for i in range(len(cps))]
     one.close()
     for n in counts:
+        free0 = torch.cuda.mem_get_info()[0]
         b = seg.ExactBatch(H, W, C, len(offs), n)
         cp = [cps[i % len(cps)] for i in range(n)]
         sp = [sps[i % len(sps)] for i in range(n)]
@@ -41,6 +42,7 @@ def main():
         steps = res[0][3]["finisher_steps"]
         print("%2d per launch: %.2f s for all, %.3f Mpixel/s, %.2f us per step per image, equal to single calls: %s" % (
             n, dt, n * H * W / dt / 1e6, dt / steps * 1e6, same), flush=True)
+        print("    workspace per image %.2f GB (device memory in use %.1f GB)" % (b.mergers[0].workspace_bytes() / 1e9, (free0 - torch.cuda.mem_get_info()[0]) / 1e9), flush=True)
         b.close()
 
 

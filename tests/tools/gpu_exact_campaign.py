@@ -64,7 +64,7 @@ if __name__ == "__main__":
     with Pool(min(16, os.cpu_count() or 4)) as pool:
         refs = pool.map(oracle_one, jobs)
     print("oracle: %d images in %.1f s" % (len(jobs), time.time() - t0), flush=True)
-    tally = {f: [0, 0, 0] for f in fams}          # equal, same event count, total
+    tally = {f: [0, 0, 0, 0, 0, 0] for f in fams}  # equal, same event count, total, images with tied pops, tied steps, tied merges
     bad = []
     tg = 0.0
     for (family, seed, rmask, rcls, rpart, rlp, rmerges, rpops) in refs:
@@ -81,12 +81,15 @@ if __name__ == "__main__":
             abs(st["total_logprob"] - rlp) <= 1e-5 * abs(rlp) and st["merges"] == rmerges
         ev = st["finisher_steps"] == rpops
         tally[family][0] += int(ok); tally[family][1] += int(ev); tally[family][2] += 1
+        tally[family][3] += int(st["tied_steps"] > 0); tally[family][4] += st["tied_steps"]; tally[family][5] += st["tied_merges"]
         if not ok:
             from mergenet_amd import labels
             agree = labels.agreement(mask, rmask) / float(mask.size)
-            bad.append((family, seed, "instances %d vs %d" % (len(classes), len(rcls)), "pixels agreeing %.4f" % agree))
+            bad.append((family, seed, "instances %d vs %d" % (len(classes), len(rcls)), "pixels agreeing %.4f" % agree,
+                        "tied steps %d merges %d" % (st["tied_steps"], st["tied_merges"])))
     for f in fams:
-        print("%-8s equal to the oracle %2d / %2d   same number of live pops %2d / %2d" %
-              (f, tally[f][0], tally[f][2], tally[f][1], tally[f][2]))
+        print("%-8s equal to the oracle %2d / %2d   same number of live pops %2d / %2d   images with tied pops %2d "
+              "(tied steps %d, of which merges %d)" %
+              (f, tally[f][0], tally[f][2], tally[f][1], tally[f][2], tally[f][3], tally[f][4], tally[f][5]))
     print("exact engine: %.1f s for %d images; mismatching: %s" % (tg, len(jobs), bad))
     sys.exit(1 if bad else 0)
