@@ -209,6 +209,13 @@ int mn_segment_launch(mn_context* ctx, const float* d_class_pred, int class_dim,
                       int* d_partition, const mn_options* opts, void* stream);
 int mn_segment_finish(mn_context* ctx, mn_stats* stats);
 
+/* Tuning aid: the sweep alone, `reps` launches back to back over `n_inputs` input sets in rotation (more than
+ * 256 MB of inputs in all keeps the Infinity Cache from serving them); average microseconds per launch. */
+int mn_sweep_time_device(mn_context* ctx, const float* const* d_class_pred, const float* const* d_adj_pred,
+                         int n_inputs, int class_dim, int offset_dim, int img_width, int img_height,
+                         int num_classes, const int* offset_list, const mn_options* opts, void* stream, int reps,
+                         float* us_per_launch);
+
 /* `count` images of ONE shape through the exact engine (MN_MODE_EXACT) together: the engine's loop is one
  * wavefront per image, so a batch is ONE launch with a workgroup per image -- images in flight are how the
  * sequential order gets throughput (the reference scales the same way, by processes: --num-jobs).  One

@@ -95,9 +95,8 @@ struct mn_context {
   int *cc_tcount, *cc_lcount;   // pixel edges per record: parallel to the components-mode table / list
   unsigned* cc_bits;            // [N] positive out-edges of every pixel (mn_cc_sign)
   int* cc_roots;                // [N] component roots (mn_cc_finish)
-  unsigned* cc_negcnt;          // negative edges per block of the sign sweep
-  int cc_sign_blocks;           // blocks of the last sign sweep (regions of the list, partial sums)
-  u64* cc_neglist;              // one region per block of the sign sweep, able to hold every edge of the block
+  int cc_sign_blocks;           // WAVES of the last sign sweep (one partial sum each)
+  unsigned* cc_negbits;         // per pixel: its negative out-edges (bit k = offset k), written by the sweep
   size_t cc_cap_max;
   hipEvent_t ev[12];   // 0-4 phases, 6-11 components-mode kernels
   // mn_segment_launch / mn_segment_finish: what the second half needs of the first
@@ -323,7 +322,7 @@ static void free_records(mn_context* c) {
 }
 
 static int ctx_alloc(mn_context* c) {
-  const size_t N = c->N, R = c->Rmax;
+  const size_t N = c->N;
   MN_HIP(dev_alloc(c, &c->ocls, N));
   MN_HIP(dev_alloc(c, &c->cls0, N));
   MN_HIP(dev_alloc(c, &c->lpvalid, N));
@@ -346,8 +345,7 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->cc_lcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->cc_bits, N));
   MN_HIP(dev_alloc(c, &c->cc_roots, N));
-  MN_HIP(dev_alloc(c, &c->cc_negcnt, N / MN_CC_SIGN_THREADS + 2));
-  MN_HIP(dev_alloc(c, &c->cc_neglist, R + ((size_t)c->maxW / 64 + 2) * 1024 * (size_t)c->maxO));
+  MN_HIP(dev_alloc(c, &c->cc_negbits, N + 16));
   // record lists and record table: sized for what the speculative components attempt can use (records
   // BETWEEN components: at most cc_cap_max); the general rounds, which hold a record per pixel edge,
   // get theirs at first use (ensure_general) -- 0.3 instead of 2.1 GB per 1024x2048 context, and a ring
@@ -356,7 +354,7 @@ static int ctx_alloc(mn_context* c) {
   if (alloc_records(c, c->cap) != MN_OK) return MN_ERR_NO_DEVICE;
   MN_HIP(dev_alloc(c, &c->block_count, N / MN_SCAN_ITEMS + 2));
   MN_HIP(dev_alloc(c, &c->wire_counts, N / MN_RLE_ITEMS + 4));
-  MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2)));
+  MN_HIP(dev_alloc(c, &c->partial, 3 * (N / 256 + 2) > 2 * (N / 64 + 8) ? 3 * (N / 256 + 2) : 2 * (N / 64 + 8)));   // (verify: 3 per block; sweep: 2 per wave)
   {
     const size_t o_sc = (sizeof(Counters) + 15) & ~(size_t)15, o_lp = o_sc + MN_NSCALARS * sizeof(int);
     MN_HIP(dev_alloc(c, &c->statblk, MN_STAT_BYTES));
@@ -427,7 +425,7 @@ extern "C" void mn_destroy(mn_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
-                 c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negcnt, c->cc_neglist,
+                 c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negbits,
                  c->block_count, c->wire_counts, c->partial, c->statblk,
                  c->bg_key, c->gmax, c->touch, c->theta, c->progress, c->d_class, c->d_same, c->d_mask, c->d_objcls, c->d_part};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
@@ -716,13 +714,24 @@ static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, 
   return MN_OK;
 }
 
+// Plane stride of the sweep's per-lane class log-products (N / 4 ints used per plane, inside the [C][N] float
+// buffer of the class sums): an odd multiple of 256 B, so that the C planes a lane writes one after the other
+// do not all start on the same memory channel (a stride of N ints is a power of two at 1024 x 2048).
+static size_t gsum_stride(int N) {
+#ifdef MN_GSUM_SKEW
+  return ((((size_t)N / 4 + 63) / 64) | 1) * 64;
+#else
+  return (size_t)N;
+#endif
+}
+
 // Component contraction (mn_kernels_cc.h).  With `wait`: returns 0 when the input is
 // sign-separable (object state + list of records between components ready, count in h_cnt), 1
 // when it is not (caller falls back), < 0 on error.  Without: everything is queued, 0 is returned
 // and the verdict is read by the caller at the end.
 template <int PX>
 static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsigned kmask, bool hook,
-                         u64* neg_list, unsigned sub_cap, bool cls = false, const unsigned* hook_bits = nullptr,
+                         bool cls = false, const unsigned* hook_bits = nullptr,
                          hipEvent_t hook_done = nullptr, bool lean_cls = false) {
   const int N = P.N, ngroups = (N + PX - 1) / PX;
   if (!hook) {
@@ -730,7 +739,7 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
     ClsOut CO;
     CO.ocls = lean_cls ? nullptr : c->ocls; CO.cls0 = c->cls0; CO.lpvalid = lean_cls ? nullptr : c->lpvalid;
     CO.gsum = reinterpret_cast<int*>(c->lpsum);     // (the summed class log-probs are written later, at roots only)
-    CO.gstride = (size_t)P.N;
+    CO.gstride = gsum_stride(P.N);
     const bool plain = !P.clip && P.sdb == 0.0f;
     // Timed: the dispatch itself carries the two events (hipExtLaunchKernel: start and stop time of THIS
     // kernel), instead of an event packet in front of it and one behind -- each of those cost a ~6 us
@@ -739,10 +748,10 @@ static void launch_cc_px(mn_context* c, const ImgParams& P, hipStream_t st, unsi
     do {                                                                                                \
       if (c->ext_events)                                                                                \
         hipExtLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, c->ev[0], c->ev[10], 0, \
-                              P, c->cc_bits, neg_list, sub_cap, c->cc_negcnt, c->scalars + 6, c->partial, CO); \
+                              P, c->cc_bits, c->cc_negbits, c->scalars + 6, c->partial, CO); \
       else                                                                                              \
-        hipLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, P, c->cc_bits, neg_list, sub_cap, \
-                           c->cc_negcnt, c->scalars + 6, c->partial, CO);                               \
+        hipLaunchKernelGGL((mn_cc_sign<PX, PLAINV, (CLSV) && PX == 4>), g, b, 0, st, P, c->cc_bits, c->cc_negbits, \
+                           c->scalars + 6, c->partial, CO);                                             \
     } while (0)
     if (plain && cls) MN_LAUNCH_SIGN(true, true);
     else if (plain) MN_LAUNCH_SIGN(true, false);
@@ -778,15 +787,12 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // to read (hipEventElapsedTime): a dozen of them per image made the HOST the bottleneck of a loop
   // over images (0.18 ms per step against 0.12 ms of kernels on the caller's stream).
   const bool lean = (c->debug_flags & 16) != 0;
-  // negative-edge list: one region per block of the sign sweep, able to hold every edge of the block
-  u64* neg_list = c->cc_neglist;
   const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
   // the sweep takes 4 pixels per lane whenever the planes stay 16-byte aligned (N % 4 == 0): with
   // W % 4 != 0 one lane per row runs over the row's end (mn_cc_sign: `straddle`)
   const bool sweep4 = (N & 3) == 0;
   const size_t sign_blocks = grid_for((size_t)(sweep4 ? N / 4 : N), MN_CC_SIGN_THREADS);
-  c->cc_sign_blocks = (int)sign_blocks;
-  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (sweep4 ? 4 : 1) * (size_t)P.O);   // per block
+  c->cc_sign_blocks = (int)(sign_blocks * (MN_CC_SIGN_THREADS / 64));       // (waves: one partial sum each)
   // class range of the components: `root` and `mapbuf` are free until the output stage
   int* clsmin = c->root;
   int* clsmax = c->mapbuf;
@@ -796,8 +802,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   const bool fused_cls = sweep4;
   // (pure components mode: the roots' class and validity flag are set by mn_cc_finish)
   const bool lean_cls = fused_cls && !cores;
-  if (sweep4) launch_cc_px<4>(c, P, st, 0u, false, neg_list, neg_cap, fused_cls, nullptr, nullptr, lean_cls);
-  else launch_cc_px<1>(c, P, st, 0u, false, neg_list, neg_cap);
+  if (sweep4) launch_cc_px<4>(c, P, st, 0u, false, fused_cls, nullptr, nullptr, lean_cls);
+  else launch_cc_px<1>(c, P, st, 0u, false);
   if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
   // debug_flags bit 11: fork right behind the sweep -- the labelling too runs on the side stream, beside
   // the next images' sweeps (the caller's stream then carries the sweeps alone)
@@ -879,8 +885,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
   fork_by_hook = fork_ext && kmask && !mid_fork;
   if (kmask) {
-    if (four) launch_cc_px<4>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
-    else launch_cc_px<1>(c, P, st, kmask, true, neg_list, neg_cap, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
+    if (four) launch_cc_px<4>(c, P, st, kmask, true, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
+    else launch_cc_px<1>(c, P, st, kmask, true, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
   }
   }
   if (c->replay.capturing) {
@@ -923,7 +929,7 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     const unsigned blocks = grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, MN_CC_SUM_THREADS);
     if (fused_cls)
       hipLaunchKernelGGL(mn_cc_sums, dim3((blocks + MN_CC_SUMS_ITERS - 1) / MN_CC_SUMS_ITERS), dim3(MN_CC_SUM_THREADS), lds, st, P, S,
-                         (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), (size_t)P.N,
+                         (const unsigned char*)c->cls0, (const int*)reinterpret_cast<int*>(c->lpsum), gsum_stride(P.N),
                          c->lp_acc, clsmin, clsmax, cores ? (const unsigned char*)c->pruned : (const unsigned char*)nullptr);
     else
       hipLaunchKernelGGL(mn_cc_class_sums, dim3(blocks), dim3(MN_CC_SUM_THREADS), lds, st, P, S, c->cls0,
@@ -931,9 +937,14 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   }
   if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[8], st));
   if (!cores)                      // (the rounds build their records from the pixel graph: positive ones too)
-  hipLaunchKernelGGL(mn_cc_cross, dim3((unsigned)sign_blocks), dim3(MN_CC_CROSS_THREADS), 0, st, P,
-                     (const int*)c->parent, T, (const u64*)neg_list, (const unsigned*)c->cc_negcnt, neg_cap,
-                     c->scalars + 6, c->cc_tcount);
+  {
+    if (sweep4)
+      hipLaunchKernelGGL(mn_cc_cross<4>, dim3((unsigned)grid_for((size_t)N / 4, MN_CC_CROSS_THREADS)), dim3(MN_CC_CROSS_THREADS),
+                         0, st, P, (const int*)c->parent, T, (const unsigned*)c->cc_negbits, c->scalars + 6, c->cc_tcount);
+    else
+      hipLaunchKernelGGL(mn_cc_cross<1>, dim3((unsigned)grid_for((size_t)N, MN_CC_CROSS_THREADS)), dim3(MN_CC_CROSS_THREADS),
+                         0, st, P, (const int*)c->parent, T, (const unsigned*)c->cc_negbits, c->scalars + 6, c->cc_tcount);
+  }
   if (!few_events && !lean) MN_HIP(hipEventRecord(c->ev[9], st));
   // Nothing waits for the verdict here: the object state and the record list are built right
   // away and the violation count travels to the host together with the record count.  If the
@@ -1704,8 +1715,7 @@ extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int c
     c->cores_used = 0;
     const bool timed = !(q.opts.debug_flags & 2) && !c->ext_events;
     if (timed) MN_HIP(hipEventRecord(c->ev[0], st));
-    launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist,
-                    (unsigned)((size_t)MN_CC_SIGN_THREADS * 4 * (size_t)P.O), true, nullptr, nullptr, true);
+    launch_cc_px<4>(c, P, st, 0u, false, true, nullptr, nullptr, true);
     if (timed) MN_HIP(hipEventRecord(c->ev[10], st));
     MN_HIP(hipGraphLaunch(rp.eA, st));
     MN_HIP(hipEventRecord(c->ev_fork, st));
@@ -1914,28 +1924,68 @@ extern "C" int mn_sweep_device(mn_context* c, const float* d_class_pred, int cla
   const bool four = (N & 3) == 0;               // (4 pixels per lane: also with W % 4 != 0, see run_components)
   const bool fused_cls = four;
   const size_t sign_blocks = grid_for((size_t)(four ? N / 4 : N), MN_CC_SIGN_THREADS);
-  const unsigned neg_cap = (unsigned)((size_t)MN_CC_SIGN_THREADS * (four ? 4 : 1) * (size_t)P.O);
+  const size_t sign_waves = sign_blocks * (MN_CC_SIGN_THREADS / 64);
   MN_HIP(hipMemsetAsync(c->scalars, 0, MN_NSCALARS * sizeof(int), st));
-  if (four) launch_cc_px<4>(c, P, st, 0u, false, c->cc_neglist, neg_cap, fused_cls);
-  else launch_cc_px<1>(c, P, st, 0u, false, c->cc_neglist, neg_cap);
+  if (four) launch_cc_px<4>(c, P, st, 0u, false, fused_cls);
+  else launch_cc_px<1>(c, P, st, 0u, false);
   MN_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_neg_out), 0x7FC00000, (size_t)P.O * N, st));
-  hipLaunchKernelGGL(mn_cc_export_neg, dim3((unsigned)sign_blocks), dim3(256), 0, st, N, (const u64*)c->cc_neglist,
-                     neg_cap, (const unsigned*)c->cc_negcnt, d_neg_out);
+  hipLaunchKernelGGL(mn_cc_export_neg, dim3((unsigned)grid_for((size_t)N, 256)), dim3(256), 0, st, P,
+                     (const unsigned*)c->cc_negbits, d_neg_out);
   MN_HIP(hipMemcpyAsync(d_bits_out, c->cc_bits, (size_t)N * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
   if (d_cls_out && fused_cls) MN_HIP(hipMemcpyAsync(d_cls_out, c->cls0, (size_t)N, hipMemcpyDeviceToDevice, st));
   if (d_gsum_out && fused_cls)          // (plane c of the sweep's products starts at c * N ints and holds N / 4 of them)
-    MN_HIP(hipMemcpy2DAsync(d_gsum_out, (size_t)(N / 4) * sizeof(int), c->lpsum, (size_t)N * sizeof(int),
+    MN_HIP(hipMemcpy2DAsync(d_gsum_out, (size_t)(N / 4) * sizeof(int), c->lpsum, gsum_stride(N) * sizeof(int),
                             (size_t)(N / 4) * sizeof(int), (size_t)P.C, hipMemcpyDeviceToDevice, st));
-  double* hp = static_cast<double*>(malloc(sign_blocks * 2 * sizeof(double)));
+  double* hp = static_cast<double*>(malloc(sign_waves * 2 * sizeof(double)));
   if (!hp) return MN_ERR_INTERNAL;
-  MN_HIP(hipMemcpyAsync(hp, c->partial, sign_blocks * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MN_HIP(hipMemcpyAsync(hp, c->partial, sign_waves * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   MN_HIP(hipMemcpyAsync(c->h_scalars, c->scalars, MN_NSCALARS * sizeof(int), hipMemcpyDeviceToHost, st));
   MN_HIP(hipStreamSynchronize(st));
   double t = 0.0;
-  for (size_t b = 0; b < sign_blocks; b++) t += hp[2 * b];
+  for (size_t b = 0; b < sign_waves; b++) t += hp[2 * b];
   free(hp);
   if (logsum_out) *logsum_out = t;
   if (info_out) { info_out[0] = four ? 4 : 1; info_out[1] = fused_cls ? 1 : 0; info_out[2] = c->h_scalars[6]; }
+  MN_HIP(hipGetLastError());
+  g_last_status = MN_OK;
+  return MN_OK;
+}
+
+// Timing of the sweep alone (tuning; see include/mergenet_hip.h): `reps` launches back to back on `stream`,
+// input set i % n_inputs for launch i, in the form the default path launches it.  Returns the average time per
+// launch by HIP events around the whole train (launch gaps of consecutive kernels included).
+extern "C" int mn_sweep_time_device(mn_context* c, const float* const* d_class_pred, const float* const* d_adj_pred,
+                                    int n_inputs, int class_dim, int offset_dim, int W, int H, int num_classes,
+                                    const int* offset_list, const mn_options* opts, void* stream, int reps,
+                                    float* us_per_launch) {
+  mn_options defaults;
+  if (!opts) { mn_default_options(&defaults); opts = &defaults; }
+  int rc = check_args(c, class_dim, offset_dim, W, H, num_classes, offset_list, opts);
+  if (rc == MN_OK && (!d_class_pred || !d_adj_pred || n_inputs < 1 || reps < 1 || !us_per_launch)) rc = MN_ERR_ARGUMENT;
+  if (rc != MN_OK) { g_last_status = rc; return rc; }
+  MN_HIP(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  c->debug_flags = opts->debug_flags | 2;          // (no events inside)
+  c->ext_events = 0;
+  c->cc_clean = 0;
+  const int N = W * H;
+  const bool four = (N & 3) == 0;
+  MN_HIP(hipMemsetAsync(c->scalars, 0, MN_NSCALARS * sizeof(int), st));
+  for (int phase = 0; phase < 2; phase++) {          // a tenth of the launches untimed first
+    const int n = phase == 0 ? (reps + 9) / 10 : reps;
+    if (phase == 1) MN_HIP(hipEventRecord(c->ev[0], st));
+    for (int i = 0; i < n; i++) {
+      ImgParams P;
+      fill_params(&P, d_class_pred[i % n_inputs], d_adj_pred[i % n_inputs], offset_dim, W, H, num_classes, offset_list, opts);
+      if (four) launch_cc_px<4>(c, P, st, 0u, false, true, nullptr, nullptr, true);
+      else launch_cc_px<1>(c, P, st, 0u, false);
+    }
+    if (phase == 1) MN_HIP(hipEventRecord(c->ev[1], st));
+  }
+  MN_HIP(hipStreamSynchronize(st));
+  float ms = 0;
+  MN_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  *us_per_launch = ms * 1e3f / (float)reps;
   MN_HIP(hipGetLastError());
   g_last_status = MN_OK;
   return MN_OK;

@@ -191,14 +191,8 @@ __device__ __forceinline__ void mn_cc_class_part(const ImgParams& P, const ClsOu
 
 template <int PX, bool PLAIN, bool CLS>
 __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
-    ImgParams P, unsigned* __restrict__ bits, u64* __restrict__ neg_list, unsigned sub_cap,
-    unsigned* __restrict__ neg_count, int* __restrict__ violations, double* __restrict__ partial,
-    ClsOut CO) {
-  __shared__ double s_part[MN_CC_SIGN_THREADS / 64];
-  __shared__ int s_w[MN_CC_SIGN_THREADS / 64];
-  __shared__ unsigned short s_item[MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS > 10240
-                                       ? 10240 : MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS];
-  constexpr int QCAP = MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS > 10240 ? 10240 : MN_CC_SIGN_THREADS * PX * MN_MAX_OFFSETS;
+    ImgParams P, unsigned* __restrict__ bits, unsigned* __restrict__ negbits, int* __restrict__ violations,
+    double* __restrict__ partial, ClsOut CO) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ngroups = (P.N + PX - 1) / PX;
   const int i = blockIdx.x * MN_CC_SIGN_THREADS + threadIdx.x;
@@ -290,89 +284,52 @@ __global__ __launch_bounds__(MN_CC_SIGN_THREADS) void mn_cc_sign(
       f = 1.0f;
     }
   }
-  int bad = 0, nneg = 0;
+  int bad = 0;
 #pragma unroll
   for (int j = 0; j < PX; j++) {
     const unsigned in = fast ? rowmask : inmask[j];
     m[j] &= in;
     ng[j] &= in;
-    nneg += __popc(ng[j]);
     bad += __popc(in & ~(m[j] | ng[j]));                // inside the rounding margin of 0.5
   }
+  // Positive and negative out-edges per pixel, 4 B each.  The negative ones become records between
+  // components in mn_cc_cross, which reads their values again (they cluster along the instance borders: a few
+  // MB).  Until round 3 the sweep itself queued them in LDS behind a block-wide scan and wrote a list of
+  // (edge, log-odds): two barriers and a dependent pass at the end of every block, 6.5 of 43.8 us (the sweep
+  // without it: 37.3 us; a kernel that only moves the sweep's bytes: 34.3 us -- tools/stream_ceiling.hip).
   if (live) {
-    if (PX == 4) mn_st_stream(reinterpret_cast<uint4*>(bits + p0), make_uint4(m[0], m[1 % PX], m[2 % PX], m[3 % PX]));
-    else bits[p0] = m[0];
+    if (PX == 4) {
+      mn_st_stream(reinterpret_cast<uint4*>(bits + p0), make_uint4(m[0], m[1 % PX], m[2 % PX], m[3 % PX]));
+      mn_st_stream(reinterpret_cast<uint4*>(negbits + p0), make_uint4(ng[0], ng[1 % PX], ng[2 % PX], ng[3 % PX]));
+    } else {
+      bits[p0] = m[0];
+      negbits[p0] = ng[0];
+    }
   }
-  // block scan of the lanes' negative-edge counts
-  int incl = nneg;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  if (lane == 63) s_w[wave] = incl;
   for (int off = 32; off > 0; off >>= 1) {
     bad += __shfl_xor(bad, off);
     t_sum += __shfl_xor(t_sum, off);
   }
   if (lane == 0) {
     if (bad) atomicAdd(violations, bad);
-    s_part[wave] = t_sum;
-  }
-  __syncthreads();
-  int woff = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < MN_CC_SIGN_THREADS / 64; w++) { if (w < wave) woff += s_w[w]; total += s_w[w]; }
-  if (threadIdx.x == 0) {
-    neg_count[blockIdx.x] = (unsigned)total;
-    double t = 0.0;                                     // block order: the sum is reproducible
-    for (int w = 0; w < MN_CC_SIGN_THREADS / 64; w++) t += s_part[w];
-    partial[(size_t)blockIdx.x * 2] = t;                // (inside + between; the split is not needed)
-    partial[(size_t)blockIdx.x * 2 + 1] = 0.0;
-  }
-  if (total == 0) return;                               // uniform
-  u64* __restrict__ mylist = neg_list + (size_t)blockIdx.x * sub_cap;
-  // queue: item = (pixel within the block << 5) | offset, at the position the scan gives
-  for (int q0 = 0; q0 < total; q0 += QCAP) {            // (one pass unless O * PX * 256 > QCAP)
-    int pos = woff + incl - nneg - q0;
-#pragma unroll
-    for (int j = 0; j < PX; j++) {
-      unsigned bitsleft = ng[j];
-      while (bitsleft) {
-        const int k = __ffs((int)bitsleft) - 1;
-        bitsleft &= bitsleft - 1u;
-        if (pos >= 0 && pos < QCAP) s_item[pos] = (unsigned short)(((threadIdx.x * PX + j) << 5) | k);
-        pos++;
-      }
-    }
-    __syncthreads();
-    const int nq = min(QCAP, total - q0);
-    for (int t = threadIdx.x; t < nq; t += MN_CC_SIGN_THREADS) {
-      const unsigned it = s_item[t];
-      const int k = (int)(it & 31u);
-      const int p = blockIdx.x * (MN_CC_SIGN_THREADS * PX) + (int)(it >> 5);
-      const float x = mn_cc_value<PLAIN>(P, P.same[(size_t)k * P.N + p]);
-      const float oml = logf(x) - mn_log1m(x);
-      if ((unsigned)(q0 + t) < sub_cap)
-        mylist[q0 + t] = ((u64)(((unsigned)k << MN_CC_EDGE_PIXBITS) | (unsigned)p) << 32) |
-                         (u64)__float_as_uint(oml);
-    }
-    __syncthreads();
+    const size_t waveg = (size_t)blockIdx.x * (MN_CC_SIGN_THREADS / 64) + wave;
+    partial[waveg * 2] = t_sum;                         // (inside + between; the split is not needed)
+    partial[waveg * 2 + 1] = 0.0;                       // wave order: the sum is reproducible
   }
 }
 
-// What the sweep leaves, for the parity test of the sweep itself (mn_sweep_device): the negative-edge
-// list (one region per block) scattered into a dense [O][N] array of log-odds.
-__global__ __launch_bounds__(256) void mn_cc_export_neg(int N, const u64* __restrict__ neg_list, unsigned sub_cap,
-                                                        const unsigned* __restrict__ neg_count,
+// What the sweep leaves, for the parity test of the sweep itself (mn_sweep_device): the negative
+// out-edges as a dense [O][N] array of log-odds (the value mn_cc_cross works with).
+__global__ __launch_bounds__(256) void mn_cc_export_neg(ImgParams P, const unsigned* __restrict__ negbits,
                                                         float* __restrict__ out) {
-  const u64* mylist = neg_list + (size_t)blockIdx.x * sub_cap;
-  const unsigned n = min(neg_count[blockIdx.x], sub_cap);
-  for (unsigned t = threadIdx.x; t < n; t += 256) {
-    const u64 e = mylist[t];
-    const unsigned hi = (unsigned)(e >> 32);
-    const unsigned k = hi >> MN_CC_EDGE_PIXBITS, p = hi & ((1u << MN_CC_EDGE_PIXBITS) - 1u);
-    out[(size_t)k * N + p] = __uint_as_float((unsigned)e);
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P.N) return;
+  unsigned left = negbits[p];
+  while (left) {
+    const int k = __ffs((int)left) - 1;
+    left &= left - 1u;
+    const float x = mn_same_value(P, P.same[(size_t)k * P.N + p]);
+    out[(size_t)k * P.N + p] = logf(x) - mn_log1m(x);
   }
 }
 
@@ -1454,49 +1411,88 @@ __device__ __forceinline__ bool mn_cc_lds_add_cnt(u64* s_key, u64* s_sum, int* s
 }
 
 
-// ---- records between components from the negative-edge list -------------------------------------
-// Every entry is an in-bounds edge with value <= sep_lo.  Both ends in one component: condition (a)
-// fails (a negative edge inside a component).  Otherwise its log-odds (2^-30 fixed point, the same
-// value mn_edge_fixed gives) go to the record of the two components: block table in LDS first --
-// the entries of a block come from neighbouring pixels and share a handful of records -- then one
-// bounded insert per record and block into the global table, with the number of pixel edges
-// alongside (certificate).  parent[] is flat here.
+// ---- records between components from the negative out-edges ------------------------------------------
+// Every set bit of `negbits` is an in-bounds edge with value <= sep_lo.  A block takes the pixels of one block
+// of the sweep: scan of the lanes' bit counts, the edges queued in LDS as 2-byte items ((pixel within the block
+// << 5) | offset) and worked off by all lanes -- a lane's own pixels hold 0..40 of them.  Both ends in one
+// component: condition (a) fails (a negative edge inside a component).  Otherwise its log-odds (2^-30 fixed
+// point: mn_edge_fixed of the value, read again here) go to the record of the two components: block table in
+// LDS first -- the entries of a block come from neighbouring pixels and share a handful of records -- then one
+// bounded insert per record and block into the global table, with the number of pixel edges alongside
+// (certificate).  parent[] is flat here.
 #define MN_CC_CROSS_THREADS 256
-#define MN_CC_CROSS_CHUNK 2048
+template <int PX>
 __global__ __launch_bounds__(MN_CC_CROSS_THREADS) void mn_cc_cross(
-    ImgParams P, const int* __restrict__ parent, HashTab T, const u64* __restrict__ neg_list,
-    const unsigned* __restrict__ neg_count, unsigned sub_cap, int* __restrict__ violations,
-    int* __restrict__ tcount) {
-  // one block per block of the sign sweep: its region of the list, its count
-  const unsigned n = min(neg_count[blockIdx.x], sub_cap);
-  if (n == 0) return;                                                  // uniform
+    ImgParams P, const int* __restrict__ parent, HashTab T, const unsigned* __restrict__ negbits,
+    int* __restrict__ violations, int* __restrict__ tcount) {
+  constexpr int QCAP = MN_CC_CROSS_THREADS * PX * MN_MAX_OFFSETS > 10240 ? 10240 : MN_CC_CROSS_THREADS * PX * MN_MAX_OFFSETS;
+  __shared__ unsigned short s_item[QCAP];
+  __shared__ int s_w[MN_CC_CROSS_THREADS / 64];
   __shared__ u64 s_key[MN_CC_EDGE_SLOTS];
   __shared__ u64 s_sum[MN_CC_EDGE_SLOTS];
   __shared__ int s_cnt[MN_CC_EDGE_SLOTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ngroups = (P.N + PX - 1) / PX;
+  const int i = blockIdx.x * MN_CC_CROSS_THREADS + threadIdx.x;
+  unsigned ng[PX];
+#pragma unroll
+  for (int j = 0; j < PX; j++) ng[j] = 0u;
+  if (i < ngroups) {
+    if (PX == 4) {
+      const uint4 t = *reinterpret_cast<const uint4*>(negbits + 4 * (size_t)i);
+      ng[0] = t.x; ng[1 % PX] = t.y; ng[2 % PX] = t.z; ng[3 % PX] = t.w;
+    } else {
+      ng[0] = negbits[i];
+    }
+  }
+  int nneg = 0;
+#pragma unroll
+  for (int j = 0; j < PX; j++) nneg += __popc(ng[j]);
+  int incl = nneg;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
   if (threadIdx.x < MN_CC_EDGE_SLOTS) {
     s_key[threadIdx.x] = MN_EMPTY; s_sum[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
   }
   __syncthreads();
-  const u64* __restrict__ list = neg_list + (size_t)blockIdx.x * sub_cap;
-  const int lane = threadIdx.x & 63;
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < MN_CC_CROSS_THREADS / 64; w++) { if (w < wave) woff += s_w[w]; total += s_w[w]; }
+  if (total == 0) return;                                              // uniform
   int bad = 0, over = 0;
-  for (unsigned base = 0; base < n; base += MN_CC_CROSS_CHUNK) {
-    for (unsigned t0 = 0; t0 < MN_CC_CROSS_CHUNK; t0 += MN_CC_CROSS_THREADS) {
-      const unsigned idx = base + t0 + threadIdx.x;
-      if (base + t0 >= n) break;                                       // uniform
+  for (int q0 = 0; q0 < total; q0 += QCAP) {                           // (one pass unless O * PX * 256 > QCAP)
+    int pos = woff + incl - nneg - q0;
+#pragma unroll
+    for (int j = 0; j < PX; j++) {
+      unsigned bitsleft = ng[j];
+      while (bitsleft) {
+        const int k = __ffs((int)bitsleft) - 1;
+        bitsleft &= bitsleft - 1u;
+        if (pos >= 0 && pos < QCAP) s_item[pos] = (unsigned short)(((threadIdx.x * PX + j) << 5) | k);
+        pos++;
+      }
+    }
+    __syncthreads();
+    const int nq = min(QCAP, total - q0);
+    for (int t0 = 0; t0 < nq; t0 += MN_CC_CROSS_THREADS) {             // (uniform trip count)
+      const int t = t0 + threadIdx.x;
       u64 key = MN_EMPTY;
       i64 sx = 0;
-      if (idx < n) {
-        const u64 e = list[idx];
-        const unsigned edge = (unsigned)(e >> 32);
-        const int k = (int)(edge >> MN_CC_EDGE_PIXBITS), p = (int)(edge & ((1u << MN_CC_EDGE_PIXBITS) - 1u));
+      if (t < nq) {
+        const unsigned it = s_item[t];
+        const int k = (int)(it & 31u);
+        const int p = blockIdx.x * (MN_CC_CROSS_THREADS * PX) + (int)(it >> 5);
         const int q = p + P.di[k] * P.W + P.dj[k];
+        const float x = mn_same_value(P, P.same[(size_t)k * P.N + p]);
         const int ru = parent[p], rv = parent[q];
         if (ru == rv) bad++;                                           // (a)
         else {
           key = mn_key(ru, rv);
-          const float oml = __uint_as_float((unsigned)(e & 0xFFFFFFFFull));
-          sx = __float2ll_rn(oml * (float)MN_FIX_ONE);                  // = mn_edge_fixed(value)
+          sx = mn_edge_fixed(x);
         }
       }
       // neighbouring entries come from neighbouring pixels: a wave often holds ONE record, and 64
@@ -1511,8 +1507,8 @@ __global__ __launch_bounds__(MN_CC_CROSS_THREADS) void mn_cc_cross(
         if (!mn_cc_lds_add_cnt(s_key, s_sum, s_cnt, T, tcount, key, sx, 1)) over++;
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x < MN_CC_EDGE_SLOTS && s_key[threadIdx.x] != MN_EMPTY)
     if (!mn_tab_insert_bounded(T, s_key[threadIdx.x], (i64)s_sum[threadIdx.x], tcount, s_cnt[threadIdx.x]))
       over++;

@@ -77,7 +77,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 _lib_handle = None
 
 EXPORTS = ["mn_default_options", "mn_create", "mn_destroy", "mn_workspace_bytes",
-           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_segment_exact_batch", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_segment_host", "c_run_segmentation",
+           "mn_segment_device", "mn_segment_launch", "mn_segment_finish", "mn_segment_exact_batch", "mn_score_device", "mn_exact_phase_a_device", "mn_sweep_device", "mn_sweep_time_device", "mn_segment_host", "c_run_segmentation",
            "mn_prepare_device", "mn_upsample_mask_device", "mn_rle_points_device", "mn_rle_encode_host", "mn_sameness_targets_device", "mn_instance_scores_device",
            "mn_pack_wire_device", "mn_runs_wire_words", "mn_pack_runs_device", "mn_unpack_runs_device",
            "mn_unpack_runs_batch_device",
@@ -123,6 +123,11 @@ def load_library() -> ctypes.CDLL:
                                            ctypes.c_int, ctypes.c_int, _i32p, _vpp, _vpp, _vpp,
                                            ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.POINTER(MnStats)]
     lib.mn_segment_exact_batch.restype = ctypes.c_int
+    if hasattr(lib, "mn_sweep_time_device"):             # (absent from older variant builds: MN_LIB)
+        lib.mn_sweep_time_device.argtypes = [ctypes.c_void_p, _vpp, _vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
+                                             ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_int, _f32p]
+        lib.mn_sweep_time_device.restype = ctypes.c_int
     lib.mn_score_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                     ctypes.POINTER(MnOptions), ctypes.c_void_p, ctypes.c_void_p,
@@ -528,6 +533,23 @@ class Merger:
         fused = bool(info[1])
         return dict(bits=bits, neg=neg, cls=cls if fused else None, gsum=gsum if fused else None,
                     logsum=logsum.value, pixels_per_lane=int(info[0]), fused_class=fused, margin_edges=int(info[2]))
+
+    def sweep_time(self, inputs: Sequence, offsets, opts: Optional[MnOptions] = None, reps: int = 400) -> float:
+        """Tuning aid (``mn_sweep_time_device``): microseconds per launch of the sweep alone, back to back over
+        the (class_probs, same_probs) pairs of ``inputs`` in rotation."""
+        C, H, W, O, off = self._check(inputs[0][0], inputs[0][1], offsets)
+        opts = opts if opts is not None else default_options()
+        n = len(inputs)
+        vp = ctypes.c_void_p * n
+        out = ctypes.c_float(0)
+        stream = self.torch.cuda.current_stream(inputs[0][0].device).cuda_stream
+        rc = self.lib.mn_sweep_time_device(self.handle, vp(*[a.data_ptr() for a, _ in inputs]),
+                                           vp(*[b.data_ptr() for _, b in inputs]), n, C, O, W, H, C,
+                                           off.ctypes.data_as(_i32p), ctypes.byref(opts), ctypes.c_void_p(stream),
+                                           int(reps), ctypes.byref(out))
+        if rc != 0:
+            raise MergeNetError(rc)
+        return out.value
 
     def exact_phase_a(self, class_probs, same_probs, offsets, opts: Optional[MnOptions] = None):
         """Phase A of the exact engine: (cls uint8[H,W], oml float32[O,H,W], prio float32[O,H,W]) in the
