@@ -882,6 +882,13 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     mid_fork = true;
   }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
+  // debug_flags bit 13: fork behind the flatten stage -- the hook joins the side stream
+  if (fork_before_sums && (c->debug_flags & 8192) && !c->replay.capturing && !cores && !early_fork && !mid_fork) {
+    MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    st = c->side;
+    mid_fork = true;
+  }
   // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
   fork_by_hook = fork_ext && kmask && !mid_fork;
   if (kmask) {

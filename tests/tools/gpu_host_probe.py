@@ -1,6 +1,7 @@
 """Where the host's time goes in the bench loop (GPU box): launch vs read-back, with and without the
 per-kernel events."""
-import sys, time
+import sys, time, faulthandler
+faulthandler.dump_traceback_later(45, exit=True)
 sys.path.insert(0, '.')
 import torch
 from collections import deque
@@ -11,11 +12,11 @@ imgs = []
 for sd in (1000, 1001, 1002, 1003):
     s = synth.synth_v1(H, W, C, offs, sd)
     imgs.append((torch.from_numpy(s.class_probs).cuda(), torch.from_numpy(s.sameness_probs).cuda()))
-for nctx in (4,):
+for nctx in (8,):
     ring_m = [seg.Merger(H, W, C, len(offs)) for _ in range(nctx)]
     outs = [(torch.empty((H, W), dtype=torch.int32, device='cuda'), torch.empty((H * W,), dtype=torch.int32, device='cuda')) for _ in range(nctx)]
     for flags in (0, 16, 16 | 32):
-        opts = seg.default_options(merge_logprob_bias=0.03, debug_flags=flags)
+        opts = seg.default_options(merge_logprob_bias=0.03, debug_flags=flags, require_proof=seg.MN_PROVE_NEVER)
         for rep in range(2):
             ring = deque(); tl = tr = 0.0
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -33,8 +34,8 @@ for nctx in (4,):
 
 # the replayed result equals the ordinary one
 m = seg.Merger(H, W, C, len(offs))
-ref, tab, _, st0 = m.segment(*imgs[1], offs, seg.default_options(merge_logprob_bias=0.03))
-o = seg.default_options(merge_logprob_bias=0.03, debug_flags=48)
+ref, tab, _, st0 = m.segment(*imgs[1], offs, seg.default_options(merge_logprob_bias=0.03, require_proof=seg.MN_PROVE_NEVER))
+o = seg.default_options(merge_logprob_bias=0.03, debug_flags=48, require_proof=seg.MN_PROVE_NEVER)
 out = (torch.empty((H, W), dtype=torch.int32, device='cuda'), torch.empty((H * W,), dtype=torch.int32, device='cuda'))
 for k in range(5):
     out[0].zero_()
