@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/mergenet_hip.h"
 #include "mn_device.h"
@@ -157,6 +158,21 @@ struct mn_context {
 };
 
 #define MN_DEFAULT_CORE_RADIUS 6
+
+// MN_TRACE_HOST=1: where the host's time goes in launch / wait / read-back (printed by mn_destroy)
+static double g_host_us[4];
+static long long g_host_n[2];
+static inline double host_now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+struct HostLaunchTimer {
+  double t0;
+  HostLaunchTimer() : t0(host_now_us()) {}
+  ~HostLaunchTimer() { g_host_us[0] += host_now_us() - t0; g_host_n[0]++; }
+};
 
 static size_t next_pow2(size_t x) {
   size_t p = 1;
@@ -423,6 +439,12 @@ extern "C" mn_context* mn_create(int device, int max_height, int max_width, int 
 
 extern "C" void mn_destroy(mn_context* c) {
   if (!c) return;
+  if (getenv("MN_TRACE_HOST") && g_host_n[1] > 0) {
+    fprintf(stderr, "host: %lld launches %.1f us each; %lld read-backs: waiting for the image %.1f us, the rest %.1f us each\n",
+            g_host_n[0], g_host_us[0] / (double)(g_host_n[0] ? g_host_n[0] : 1), g_host_n[1],
+            g_host_us[1] / (double)g_host_n[1], g_host_us[2] / (double)g_host_n[1]);
+    g_host_n[0] = g_host_n[1] = 0; g_host_us[0] = g_host_us[1] = g_host_us[2] = 0.0;
+  }
   (void)hipSetDevice(c->device);
   void* dev[] = {c->ocls, c->cls0, c->lpvalid, c->matched, c->pruned, c->osize, c->parent, c->mate, c->root,
                  c->label, c->mapbuf, c->lpsum, c->lp_acc, c->ball, c->bsub, c->fin_lists, c->cc_tcount, c->cc_lcount, c->cc_bits, c->cc_roots, c->cc_negbits,
@@ -1685,6 +1707,7 @@ extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int c
                                  int* d_object_class, int* d_partition, const mn_options* opts,
                                  void* stream) {
   if (!c || c->pend.active) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+  HostLaunchTimer host_timer;
   mn_context::Pending& q = c->pend;
   if (opts) q.opts = *opts; else mn_default_options(&q.opts);
   q.d_class = d_class_pred; q.class_dim = class_dim; q.d_adj = d_adj_pred; q.offset_dim = offset_dim;
@@ -1774,6 +1797,8 @@ extern "C" int mn_segment_launch(mn_context* c, const float* d_class_pred, int c
 // attempt that does not hold is redone here on the ordinary path) and fill `stats`.
 extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
   if (!c || !c->pend.active) { g_last_status = MN_ERR_ARGUMENT; return MN_ERR_ARGUMENT; }
+  const double t_in = host_now_us();
+  double t_synced = t_in;
   mn_context::Pending& q = c->pend;
   int rc;
   // require_proof: 1 = always, -1 = never, 0 = by mode -- AUTO hands back proven results only, an
@@ -1786,6 +1811,7 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
   } else {
     MN_HIP(hipSetDevice(c->device));
     MN_HIP(hipEventSynchronize(c->ev_done));
+    t_synced = host_now_us();
     memset(&q.stats, 0, sizeof(q.stats));
     rc = segment_read_back(c, &q.opts, q.mode, true, q.finish_limit, q.N, q.R0, q.rounds, q.want_cert,
                            &q.stats);
@@ -1812,6 +1838,7 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
   }
   if (stats) *stats = q.stats;
   q.active = 0;
+  g_host_us[1] += t_synced - t_in; g_host_us[2] += host_now_us() - t_synced; g_host_n[1]++;
   return rc;
 }
 

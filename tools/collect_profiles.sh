@@ -36,3 +36,11 @@ cp $(find $ROOT/gpurun_out/${TAG}_exact -name '*kernel_stats.csv' | head -1) $RO
 cd $ROOT
 python tests/tools/gpu_exact_campaign.py 8 > gpurun_out/$TAG/exact_campaign.log 2>&1
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact --no-general-path --no-pipelined > gpurun_out/$TAG/bench_line_steps20_warmup5.json 2>> gpurun_out/$TAG/bench.err
+# the memory system's ceiling for the sweep's traffic, and the sweep alone back to back
+tools/stream_ceiling > gpurun_out/$TAG/stream_ceiling.log 2>&1
+python tests/tools/gpu_sweep_time.py > gpurun_out/$TAG/sweep_alone.log 2>&1
+MN_H=800 MN_W=1333 MN_C=81 MN_OA=80,16 python tests/tools/gpu_sweep_time.py > gpurun_out/$TAG/sweep_alone_cfg5.log 2>&1
+# the exact engine, batches in one launch
+python tests/tools/gpu_exact_batch.py 1 64 192 > gpurun_out/$TAG/exact_batch.log 2>&1
+python tests/tools/gpu_exact_ties.py > gpurun_out/$TAG/exact_ties.log 2>&1
+bash tools/prof_default_bench.sh $TAG > gpurun_out/$TAG/default_command.txt 2>&1
