@@ -67,6 +67,8 @@ enum mn_mode {
                             ROUNDS when the input is not sign-separable (mode_used tells)         */
 };
 
+enum mn_tie_order { MN_TIES_LOWEST_ID = 0, MN_TIES_REFERENCE = 1 };
+
 typedef struct mn_options {
   float same_different_bias;   /* segment.h:246 */
   float object_merge_factor;   /* segment.h:247 */
@@ -121,6 +123,14 @@ typedef struct mn_options {
                                   ahead of the rounds -- when all its short edges are positive and
                                   same-class (0 = default; < 0 = every offset
                                   is short: the widest fringe, the closest to the reference's order)   */
+  int tie_order;               /* MN_MODE_EXACT (and what AUTO redoes by it): who goes first among records with
+                                  bit-equal priorities.  MN_TIES_LOWEST_ID (0, default): the record created
+                                  first -- the exact engine.  MN_TIES_REFERENCE (1): what the reference's
+                                  std::priority_queue and std::unordered_map (libstdc++, GCC 11: the build the
+                                  golden vectors come from) make of it -- binary-heap position and hash-map
+                                  iteration order, restated on flat arrays (mn_reforder.h) and run by ONE lane: the
+                                  reference's very partition also on maps with plateaus of equal values, at
+                                  ~10x the time per step (csegment variant only; small images)             */
 } mn_options;
 
 typedef struct mn_stats {

@@ -23,6 +23,7 @@
 #include "mn_kernels_tail.h"
 #include "mn_kernels_oc.h"
 #include "mn_kernels_exact.h"
+#include "mn_kernels_reforder.h"
 
 // Counters | 16 int scalars | 4 doubles, each part 16-byte aligned
 // scalars: [0] edge violations [1] instances [2] objects [3] class violations [4] record violations
@@ -152,6 +153,16 @@ struct mn_context {
     int arena_extra;              // arena words per pixel beyond the initial arrays (doubled when a run fills it)
     int table_shift;              // pair table: buckets = next_pow2(records >> table_shift)
   } xw;
+  // the reference-order loop (mn_options.tie_order = MN_TIES_REFERENCE, mn_kernels_reforder.h)
+  struct RWork {
+    RoState S;
+    void* block;                  // one allocation for all arrays
+    size_t bytes;
+    int n_pix; long long n_rec; int n_cls; long long arena_cap, heap_cap;
+    int arena_per_pixel, heap_per_record;     // (doubled when a run fills them)
+    long long* h_ctl;             // pinned
+  } rw;
+  int tie_ref;                    // this attempt runs the reference-order loop
   // staging for the host-pointer entry points
   float *d_class, *d_same;
   int *d_mask, *d_objcls, *d_part;
@@ -199,6 +210,15 @@ static void x_free(mn_context* c) {
   memset(&c->xw, 0, sizeof(c->xw));
   c->xw.d_P = keep.d_P; c->xw.d_X = keep.d_X; c->xw.batch_cap = keep.batch_cap;
   c->xw.arena_extra = keep.arena_extra; c->xw.table_shift = keep.table_shift;
+}
+
+static void r_free(mn_context* c) {
+  if (c->rw.block) (void)hipFree(c->rw.block);
+  if (c->rw.h_ctl) (void)hipHostFree(c->rw.h_ctl);
+  c->bytes -= c->rw.bytes;
+  const int ap = c->rw.arena_per_pixel, hp = c->rw.heap_per_record;
+  memset(&c->rw, 0, sizeof(c->rw));
+  c->rw.arena_per_pixel = ap; c->rw.heap_per_record = hp;
 }
 
 template <typename T>
@@ -453,6 +473,7 @@ extern "C" void mn_destroy(mn_context* c) {
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   x_free(c);
+  r_free(c);
   if (c->xw.d_P) (void)hipFree(c->xw.d_P);
   if (c->xw.d_X) (void)hipFree(c->xw.d_X);
   free_records(c);
@@ -1194,11 +1215,111 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
   return MN_OK;
 }
 
+// ---- the reference-order loop (tie_order = MN_TIES_REFERENCE): workspace, launches ---------------------
+// Per record: two list nodes (12 B each), ends, log-odds, priority (16 B), queue entries (8 B x 3: the
+// reference's queue holds up to 2.4 entries per record, stale ones included); per pixel: object state, map
+// header, bucket arrays (13 + 29 + ... entries as the maps grow: 95-200 per pixel measured).
+static int r_ensure(mn_context* c, int N, int O, int C) {
+  mn_context::RWork& w = c->rw;
+  if (w.arena_per_pixel <= 0) { w.arena_per_pixel = 16 * O + 64; w.heap_per_record = 3; }
+  const long long NL = (long long)N * O;
+  const long long arena_cap = (long long)N * w.arena_per_pixel + 65536;
+  const long long heap_cap = NL * w.heap_per_record + 65536;
+  if (NL > (1LL << 28)) return MN_ERR_CAPACITY;          // (node ids 2 * record + side are ints)
+  if (!(w.block && w.n_pix >= N && w.n_rec >= NL && w.arena_cap >= arena_cap && w.heap_cap >= heap_cap)) {
+    r_free(c);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_osize = take((size_t)N * 4), o_ocls = take((size_t)N * 4), o_bcount = take((size_t)N * 4),
+                 o_nelem = take((size_t)N * 4), o_head = take((size_t)N * 4), o_boff = take((size_t)N * 8),
+                 o_single = take((size_t)N * 4), o_barena = take((size_t)arena_cap * 4),
+                 o_nnext = take((size_t)NL * 2 * 4), o_nkey = take((size_t)NL * 2 * 8), o_r1 = take((size_t)NL * 4),
+                 o_r2 = take((size_t)NL * 4), o_oml = take((size_t)NL * 4), o_prio = take((size_t)NL * 4),
+                 o_hprio = take((size_t)heap_cap * 4), o_hrec = take((size_t)heap_cap * 4), o_ctl = take(64);
+    MN_HIP(hipMalloc(&w.block, off));
+    MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), 64));
+    w.bytes = off;
+    c->bytes += off;
+    char* b = static_cast<char*>(w.block);
+    RoState& S = w.S;
+    S.osize = reinterpret_cast<int*>(b + o_osize); S.ocls = reinterpret_cast<int*>(b + o_ocls);
+    S.bcount = reinterpret_cast<int*>(b + o_bcount); S.nelem = reinterpret_cast<int*>(b + o_nelem);
+    S.head = reinterpret_cast<int*>(b + o_head); S.boff = reinterpret_cast<long long*>(b + o_boff);
+    S.single = reinterpret_cast<int*>(b + o_single); S.barena = reinterpret_cast<int*>(b + o_barena);
+    S.nnext = reinterpret_cast<int*>(b + o_nnext); S.nkey = reinterpret_cast<unsigned long long*>(b + o_nkey);
+    S.r1 = reinterpret_cast<int*>(b + o_r1); S.r2 = reinterpret_cast<int*>(b + o_r2);
+    S.oml = reinterpret_cast<float*>(b + o_oml); S.prio = reinterpret_cast<float*>(b + o_prio);
+    S.hprio = reinterpret_cast<float*>(b + o_hprio); S.hrec = reinterpret_cast<int*>(b + o_hrec);
+    S.ctl = reinterpret_cast<long long*>(b + o_ctl);
+    w.n_pix = N; w.n_rec = NL; w.n_cls = C; w.arena_cap = arena_cap; w.heap_cap = heap_cap;
+  }
+  w.S.N = N; w.S.C = C; w.S.NL = NL;
+  w.S.barena_cap = w.arena_cap; w.S.hcap = w.heap_cap;
+  return MN_OK;
+}
+
+// The exact engine's set-up (class vectors, records with the reference's log-odds), then ONE lane runs the
+// reference's constructor loop and merge loop on its containers (mn_reforder.h); a run that fills the bucket
+// arena or the queue is repeated with twice as much.
+static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
+  if (P.variant != MN_VARIANT_CSEGMENT) return MN_ERR_ARGUMENT;
+  long long per_launch = 1LL << 20;                  // pops per launch (MN_X_BUDGET: tests of the relaunch)
+  if (const char* e = getenv("MN_X_BUDGET")) { const long long v = atoll(e); if (v > 0) per_launch = v; }
+  for (int attempt = 0; attempt < 6; attempt++) {
+    int rc = exact_setup(c, P, st);
+    if (rc != MN_OK) return rc;
+    rc = r_ensure(c, P.N, P.O, P.C);
+    if (rc != MN_OK) return rc;
+    mn_context::RWork& w = c->rw;
+    XState& X = c->xw.X;
+    RoState S = w.S;
+    S.lp = X.lp; S.parent = X.parent; S.omf = P.omf; S.bias = P.bias;
+    hipLaunchKernelGGL(mn_ro_prepare_objects, dim3(grid_for((size_t)P.N, 256)), dim3(256), 0, st, P, X, S);
+    hipLaunchKernelGGL(mn_ro_prepare_records, dim3(grid_for((size_t)S.NL, 256)), dim3(256), 0, st, P, X, S);
+    MN_HIP(hipGetLastError());
+    // every lane-0 loop ends: the reference pops each queue entry once, and a record is pushed at most once per
+    // re-score; 64 pops per initial record is far beyond what it does (4-5)
+    const long long max_pops = 64LL * S.NL + 65536;
+    long long status = MN_RO_RUNNING;
+    for (long long it = 0; it < (1 << 20); it++) {
+      hipLaunchKernelGGL(mn_ro_loop, dim3(1), dim3(64), 0, st, S, P.O, per_launch);
+      MN_HIP(hipGetLastError());
+      MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 64, hipMemcpyDeviceToHost, st));
+      MN_HIP(hipStreamSynchronize(st));
+      status = w.h_ctl[0];
+      if (status != MN_RO_BUDGET) break;
+      if (w.h_ctl[3] > max_pops) { status = MN_RO_CORRUPT; break; }
+    }
+    if (getenv("MN_TRACE_EXACT"))
+      fprintf(stderr, "reference-order loop: status %lld pops %lld merges %lld bucket arena %lld of %lld largest queue %lld of %lld\n",
+              status, w.h_ctl[3], w.h_ctl[4], w.h_ctl[2], w.arena_cap, w.h_ctl[6], w.heap_cap);
+    if (status == MN_RO_ARENA_FULL) { w.arena_per_pixel *= 2; continue; }
+    if (status == MN_RO_HEAP_FULL) { w.heap_per_record *= 2; continue; }
+    if (status != MN_RO_DONE) {
+      fprintf(stderr, "mergenet_hip: reference-order loop stopped with status %lld after %lld pops\n", status, w.h_ctl[3]);
+      return MN_ERR_INTERNAL;
+    }
+    const size_t n = (size_t)S.NL > (size_t)P.N ? (size_t)S.NL : (size_t)P.N;
+    hipLaunchKernelGGL(mn_ro_finish, dim3(grid_for(n, 256)), dim3(256), 0, st, P, X, S);
+    MN_HIP(hipGetLastError());
+    XCtl* h = c->xw.h_ctl;
+    h->steps = w.h_ctl[3]; h->merges = w.h_ctl[4];
+    h->tied_steps = 0; h->tied_merges = 0;           // (ties are resolved as the reference resolves them)
+    return MN_OK;
+  }
+  return MN_ERR_CAPACITY;
+}
+
 // set-up, loop and hand-over of ONE image; in a batch (mn_segment_exact_batch) set-up and loop have run for
 // all images together and only the hand-over is left (xw.prerun)
 static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   int rc = MN_OK;
-  if (!c->xw.prerun) {
+  if (c->tie_ref && !c->xw.prerun) {
+    rc = run_reforder(c, P, st);
+    if (rc != MN_OK) return rc;
+    MN_HIP(hipEventRecord(c->ev[1], st));
+    MN_HIP(hipEventRecord(c->ev[2], st));
+  } else if (!c->xw.prerun) {
     mn_context* one[1] = {c};
     rc = exact_run(one, 1, &P, st);
     if (rc != MN_OK) return rc;
@@ -1338,6 +1459,7 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // the sequential order at any size: the exact engine (debug_flags bit 8 keeps the small-list finisher
   // with its O(R) arg-max per step, for comparison)
   const bool xengine = mode == MN_MODE_EXACT && (!(opts->debug_flags & 256) || c->xw.prerun);
+  c->tie_ref = xengine && opts->tie_order == MN_TIES_REFERENCE;
   ObjState S = obj_state(c);
   // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
   // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph

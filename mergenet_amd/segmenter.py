@@ -36,6 +36,7 @@ MN_DEBUG_LEAN_EVENTS, MN_DEBUG_REPLAY = 16, 32
 MN_DEBUG_CLUSTERS = 512           # general rounds: contract order-free clusters of objects (opt-in)
 MN_DEBUG_OLD_EXACT = 256          # MN_MODE_EXACT by the small-list finisher instead of the exact engine
 MN_PROVE_ALWAYS, MN_PROVE_BY_MODE, MN_PROVE_NEVER = 1, 0, -1   # mn_options.require_proof
+MN_TIES_LOWEST_ID, MN_TIES_REFERENCE = 0, 1                    # mn_options.tie_order
 MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
 
 SegmenterOptions = namedtuple("SegmenterOptions",
@@ -50,7 +51,8 @@ class MnOptions(ctypes.Structure):
                 ("subrounds", ctypes.c_int), ("prune_threshold", ctypes.c_float),
                 ("compute_logprob", ctypes.c_int), ("no_handover_refresh", ctypes.c_int),
                 ("band_permille", ctypes.c_int), ("debug_flags", ctypes.c_int),
-                ("require_proof", ctypes.c_int), ("core_radius", ctypes.c_int)]
+                ("require_proof", ctypes.c_int), ("core_radius", ctypes.c_int),
+                ("tie_order", ctypes.c_int)]
 
 
 class MnStats(ctypes.Structure):

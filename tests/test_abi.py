@@ -34,7 +34,7 @@ def test_option_struct_layout_matches_header():
     o = seg.default_options()
     assert abs(o.merge_logprob_bias - 0.03) < 1e-7 and o.object_merge_factor == 1.0
     assert o.variant == seg.MN_VARIANT_CSEGMENT and o.prune_threshold == 200.0
-    assert ctypes.sizeof(seg.MnOptions) == 16 * 4
+    assert ctypes.sizeof(seg.MnOptions) == 17 * 4      # + tie_order
     assert ctypes.sizeof(seg.MnStats) == 10 * 4 + 2 * 8 + 8 + 10 * 4 + 4 * 4   # + proof, cores_condemned, tied_steps, tied_merges
 
 
