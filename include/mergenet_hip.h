@@ -67,7 +67,8 @@ enum mn_mode {
                             ROUNDS when the input is not sign-separable (mode_used tells)         */
 };
 
-enum mn_tie_order { MN_TIES_LOWEST_ID = 0, MN_TIES_REFERENCE = 1 };
+enum mn_tie_order { MN_TIES_DEFAULT = 0, MN_TIES_REFERENCE = 1, MN_TIES_LOWEST_ID = 2 };
+#define MN_TIE_LIMIT_RECORDS 400000   /* MN_TIES_DEFAULT: largest image (initial records) redone in the reference's order */
 
 typedef struct mn_options {
   float same_different_bias;   /* segment.h:246 */
@@ -124,13 +125,18 @@ typedef struct mn_options {
                                   same-class (0 = default; < 0 = every offset
                                   is short: the widest fringe, the closest to the reference's order)   */
   int tie_order;               /* MN_MODE_EXACT (and what AUTO redoes by it): who goes first among records with
-                                  bit-equal priorities.  MN_TIES_LOWEST_ID (0, default): the record created
-                                  first -- the exact engine.  MN_TIES_REFERENCE (1): what the reference's
+                                  bit-equal priorities.  MN_TIES_LOWEST_ID: the record created first -- the
+                                  exact engine's own rule.  MN_TIES_REFERENCE: what the reference's
                                   std::priority_queue and std::unordered_map (libstdc++, GCC 11: the build the
                                   golden vectors come from) make of it -- binary-heap position and hash-map
-                                  iteration order, restated on flat arrays (mn_reforder.h) and run by ONE lane: the
-                                  reference's very partition also on maps with plateaus of equal values, at
-                                  ~10x the time per step (csegment variant only; small images)             */
+                                  iteration order, restated on flat arrays (mn_reforder.h); the maps are worked
+                                  by ONE lane, the heap by its wave: the reference's very partition also on
+                                  maps with plateaus of equal values, at 20-40x the exact engine's time
+                                  (csegment variant only).  MN_TIES_DEFAULT (0): the exact engine first; if it
+                                  met tied pops (stats.tied_steps > 0: only then can the two rules differ) and
+                                  the image has at most MN_TIE_LIMIT_RECORDS initial records, it is redone in
+                                  the reference's order; larger images keep the exact engine's answer and
+                                  say so (stats.tie_order_used, stats.tied_steps)                          */
 } mn_options;
 
 typedef struct mn_stats {
@@ -174,6 +180,8 @@ typedef struct mn_stats {
                                   the two orders usually commute, DESIGN.md section 5 has the inputs where
                                   they do not (radius-4 blurred, clipped maps)                             */
   int tied_merges;             /* ... of which were merges */
+  int tie_order_used;          /* MN_MODE_EXACT: MN_TIES_LOWEST_ID or MN_TIES_REFERENCE (0 on the other paths) */
+  int reserved_i;
 } mn_stats;
 
 typedef struct mn_context mn_context;

@@ -162,7 +162,8 @@ struct mn_context {
     int arena_per_pixel, heap_per_record;     // (doubled when a run fills them)
     long long* h_ctl;             // pinned
   } rw;
-  int tie_ref;                    // this attempt runs the reference-order loop
+  int tie_ref;                    // this attempt: MN_TIES_* as asked for
+  int tie_used;                   // ... and what the last exact attempt ran in the end
   // staging for the host-pointer entry points
   float *d_class, *d_same;
   int *d_mask, *d_objcls, *d_part;
@@ -1221,7 +1222,11 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
 // header, bucket arrays (13 + 29 + ... entries as the maps grow: 95-200 per pixel measured).
 static int r_ensure(mn_context* c, int N, int O, int C) {
   mn_context::RWork& w = c->rw;
-  if (w.arena_per_pixel <= 0) { w.arena_per_pixel = 16 * O + 64; w.heap_per_record = 3; }
+  if (w.arena_per_pixel <= 0) {
+    w.arena_per_pixel = 16 * O + 64; w.heap_per_record = 3;
+    if (const char* e = getenv("MN_RO_ARENA_PER_PIXEL")) { const int v = atoi(e); if (v > 0) w.arena_per_pixel = v; }   // (tests)
+    if (const char* e = getenv("MN_RO_HEAP_PER_RECORD")) { const int v = atoi(e); if (v > 0) w.heap_per_record = v; }
+  }
   const long long NL = (long long)N * O;
   const long long arena_cap = (long long)N * w.arena_per_pixel + 65536;
   const long long heap_cap = NL * w.heap_per_record + 65536;
@@ -1235,9 +1240,9 @@ static int r_ensure(mn_context* c, int N, int O, int C) {
                  o_single = take((size_t)N * 4), o_barena = take((size_t)arena_cap * 4),
                  o_nnext = take((size_t)NL * 2 * 4), o_nkey = take((size_t)NL * 2 * 8), o_r1 = take((size_t)NL * 4),
                  o_r2 = take((size_t)NL * 4), o_oml = take((size_t)NL * 4), o_prio = take((size_t)NL * 4),
-                 o_hprio = take((size_t)heap_cap * 4), o_hrec = take((size_t)heap_cap * 4), o_ctl = take(64);
+                 o_hprio = take((size_t)heap_cap * 4), o_hrec = take((size_t)heap_cap * 4), o_ctl = take(128);
     MN_HIP(hipMalloc(&w.block, off));
-    MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), 64));
+    MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), 128));
     w.bytes = off;
     c->bytes += off;
     char* b = static_cast<char*>(w.block);
@@ -1284,15 +1289,17 @@ static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
     for (long long it = 0; it < (1 << 20); it++) {
       hipLaunchKernelGGL(mn_ro_loop, dim3(1), dim3(64), 0, st, S, P.O, per_launch);
       MN_HIP(hipGetLastError());
-      MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 64, hipMemcpyDeviceToHost, st));
+      MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 128, hipMemcpyDeviceToHost, st));
       MN_HIP(hipStreamSynchronize(st));
       status = w.h_ctl[0];
       if (status != MN_RO_BUDGET) break;
       if (w.h_ctl[3] > max_pops) { status = MN_RO_CORRUPT; break; }
     }
     if (getenv("MN_TRACE_EXACT"))
-      fprintf(stderr, "reference-order loop: status %lld pops %lld merges %lld bucket arena %lld of %lld largest queue %lld of %lld\n",
-              status, w.h_ctl[3], w.h_ctl[4], w.h_ctl[2], w.arena_cap, w.h_ctl[6], w.heap_cap);
+      fprintf(stderr, "reference-order loop: status %lld pops %lld merges %lld bucket arena %lld of %lld largest queue %lld of %lld; "
+              "seconds: constructor's loop %.2f, pops (and stores of fresh priorities) %.2f, merges %.2f\n",
+              status, w.h_ctl[3], w.h_ctl[4], w.h_ctl[2], w.arena_cap, w.h_ctl[6], w.heap_cap,
+              (double)w.h_ctl[8] * 1e-8, (double)w.h_ctl[9] * 1e-8, (double)w.h_ctl[10] * 1e-8);
     if (status == MN_RO_ARENA_FULL) { w.arena_per_pixel *= 2; continue; }
     if (status == MN_RO_HEAP_FULL) { w.heap_per_record *= 2; continue; }
     if (status != MN_RO_DONE) {
@@ -1314,15 +1321,31 @@ static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
 // all images together and only the hand-over is left (xw.prerun)
 static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
   int rc = MN_OK;
-  if (c->tie_ref && !c->xw.prerun) {
+  c->tie_used = MN_TIES_LOWEST_ID;
+  const bool ref_possible = P.variant == MN_VARIANT_CSEGMENT;       // (the Python variant's heapq / dict order is not restated)
+  if (c->tie_ref == MN_TIES_REFERENCE && !c->xw.prerun) {
+    if (!ref_possible) return MN_ERR_ARGUMENT;
     rc = run_reforder(c, P, st);
     if (rc != MN_OK) return rc;
+    c->tie_used = MN_TIES_REFERENCE;
     MN_HIP(hipEventRecord(c->ev[1], st));
     MN_HIP(hipEventRecord(c->ev[2], st));
   } else if (!c->xw.prerun) {
     mn_context* one[1] = {c};
     rc = exact_run(one, 1, &P, st);
     if (rc != MN_OK) return rc;
+    // MN_TIES_DEFAULT: tied pops are the only place where the engine's order and the reference's can part; a
+    // small image that had some is redone the reference's way
+    long long limit = MN_TIE_LIMIT_RECORDS;
+    if (const char* e = getenv("MN_TIE_LIMIT")) limit = atoll(e);
+    if (c->tie_ref == MN_TIES_DEFAULT && ref_possible && c->xw.h_ctl->tied_steps > 0 &&
+        (long long)P.N * P.O <= limit) {
+      const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
+      rc = run_reforder(c, P, st);
+      if (rc != MN_OK) return rc;
+      c->tie_used = MN_TIES_REFERENCE;
+      c->xw.h_ctl->tied_steps = ts; c->xw.h_ctl->tied_merges = tm;     // (what the exact engine met)
+    }
   } else {
     MN_HIP(hipEventRecord(c->ev[1], st));
     MN_HIP(hipEventRecord(c->ev[2], st));
@@ -1370,7 +1393,9 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->cores_condemned = c->cores_used ? (c->h_scalars[9] != 0) : 0;
     stats->finisher_steps = c->h_cnt->finisher_steps;
     stats->tied_steps = stats->tied_merges = 0;
+    stats->tie_order_used = 0;
     if (mode == MN_MODE_EXACT && c->xw.h_ctl && (!(opts->debug_flags & 256) || c->xw.prerun)) {
+      stats->tie_order_used = c->tie_used;
       const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
       stats->tied_steps = (int)(ts > 0x7FFFFFFF ? 0x7FFFFFFF : ts);
       stats->tied_merges = (int)(tm > 0x7FFFFFFF ? 0x7FFFFFFF : tm);
@@ -1459,7 +1484,8 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   // the sequential order at any size: the exact engine (debug_flags bit 8 keeps the small-list finisher
   // with its O(R) arg-max per step, for comparison)
   const bool xengine = mode == MN_MODE_EXACT && (!(opts->debug_flags & 256) || c->xw.prerun);
-  c->tie_ref = xengine && opts->tie_order == MN_TIES_REFERENCE;
+  c->tie_ref = xengine ? opts->tie_order : MN_TIES_LOWEST_ID;
+  c->tie_used = 0;
   ObjState S = obj_state(c);
   // the same conditions let the general rounds start from the cores (mn_core_clean) instead of from
   // single pixels; debug_flags bit 2 keeps the round on the implicit pixel graph

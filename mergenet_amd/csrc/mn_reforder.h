@@ -249,24 +249,32 @@ MN_REF_HD float mn_ro_score(const RoState& S, int r, int* mcls_out) {
 
 // The constructor's loop (segment.cc:209-231) from `cursor` on: records in creation order into the maps of
 // both ends (the source pixel's first) and, if >= 0, into the queue.  `src[r]` is the source pixel of slot r.
+MN_REF_HD int mn_ro_init_record(RoState& S, int O, long long r) {        // record slot r into the maps of both ends
+  const int p = (int)(r / O);                            // the source pixel of slot r = pixel * O + k
+  const int a = S.r1[r], b = S.r2[r];
+  const int q = a == p ? b : a;
+  const unsigned long long key = mn_ro_key(a, b);
+  if (!mn_ro_insert(S, p, (int)(2 * r), key)) return MN_RO_ARENA_FULL;
+  if (!mn_ro_insert(S, q, (int)(2 * r + 1), key)) return MN_RO_ARENA_FULL;
+  return MN_RO_RUNNING;
+}
+
 MN_REF_HD int mn_ro_init(RoState& S, int O, long long budget) {
   long long r = S.ctl[5];
   for (; r < S.NL && budget > 0; r++, budget--) {
     if (S.r1[r] < 0) continue;
-    const int p = (int)(r / O);                           // the source pixel of slot r = pixel * O + k
-    const int a = S.r1[r], b = S.r2[r];
-    const int q = a == p ? b : a;
-    const unsigned long long key = mn_ro_key(a, b);
-    if (!mn_ro_insert(S, p, (int)(2 * r), key)) { S.ctl[5] = r; return MN_RO_ARENA_FULL; }
-    if (!mn_ro_insert(S, q, (int)(2 * r + 1), key)) { S.ctl[5] = r; return MN_RO_ARENA_FULL; }
+    const int rc = mn_ro_init_record(S, O, r);
+    if (rc != MN_RO_RUNNING) { S.ctl[5] = r; return rc; }
     if (S.prio[r] >= 0.0f && !mn_ro_push(S, S.prio[r], (int)r)) { S.ctl[5] = r; return MN_RO_HEAP_FULL; }
   }
   S.ctl[5] = r;
   return r >= S.NL ? MN_RO_DONE : MN_RO_BUDGET;
 }
 
-// Merge (segment.cc:602-727)
-MN_REF_HD int mn_ro_merge(RoState& S, int r, int mcls) {
+// Merge (segment.cc:602-727) in three pieces, so that the device can put a wave-wide push between the records
+// of the walk: begin (survivor's state, the merged record leaves both maps; returns the first node of the
+// absorbed object's list), one record of the walk (may ask for ONE push: *push_rec >= 0), end.
+MN_REF_HD int mn_ro_merge_begin(RoState& S, int r, int mcls, int* a_out, int* b_out, int* first) {
   int a = S.r1[r], b = S.r2[r];
   if (S.osize[a] < S.osize[b]) { const int t = a; a = b; b = t; }     // the larger survives, a tie keeps r1
   S.ocls[a] = mcls;
@@ -277,40 +285,60 @@ MN_REF_HD int mn_ro_merge(RoState& S, int r, int mcls) {
   const unsigned long long rk = mn_ro_key(S.r1[r], S.r2[r]);
   if (mn_ro_erase(S, a, rk) == MN_RO_NULL) return MN_RO_CORRUPT;
   if (mn_ro_erase(S, b, rk) == MN_RO_NULL) return MN_RO_CORRUPT;
-  for (int it = S.head[b]; it != MN_RO_NULL;) {
-    const int nx = S.nnext[it];                          // (the iterator's increment: this node's slot is reused below)
-    const int t = it >> 1;
-    int c3;
-    const unsigned long long old_key = mn_ro_key(S.r1[t], S.r2[t]);
-    if (S.r1[t] == b) c3 = S.r2[t]; else c3 = S.r1[t];
-    const int lo = a < c3 ? a : c3, hi = a < c3 ? c3 : a;
-    const unsigned long long new_key = mn_ro_key(lo, hi);
-    const int n3 = mn_ro_erase(S, c3, old_key);
-    if (n3 == MN_RO_NULL) return MN_RO_CORRUPT;
-    int prev;
-    const int hit = mn_ro_find(S, a, new_key, &prev);
-    if (hit != MN_RO_NULL) {
-      const int u = hit >> 1;
-      S.oml[u] += S.oml[t];
-      S.prio[t] = 1.17549435e-38f;                       // numeric_limits<float>::min(): never equals a queue entry
-      S.r1[t] = lo; S.r2[t] = hi;                        // (the folded record keeps two live ends, segment.cc:658-663)
-      int mc;
-      S.prio[u] = mn_ro_score(S, u, &mc);
-      if (S.prio[u] >= 0.0f && !mn_ro_push(S, S.prio[u], u)) return MN_RO_HEAP_FULL;
-    } else {
-      S.r1[t] = lo; S.r2[t] = hi;
-      if (!mn_ro_insert(S, a, it, new_key)) return MN_RO_ARENA_FULL;       // the slot b's map held
-      if (!mn_ro_insert(S, c3, n3, new_key)) return MN_RO_ARENA_FULL;
-      int mc;
-      S.prio[t] = mn_ro_score(S, t, &mc);
-      if (S.prio[t] >= 0.0f && !mn_ro_push(S, S.prio[t], t)) return MN_RO_HEAP_FULL;
-    }
-    it = nx;
+  *a_out = a; *b_out = b; *first = S.head[b];
+  return MN_RO_RUNNING;
+}
+
+MN_REF_HD int mn_ro_merge_node(RoState& S, int a, int b, int it, int* next, float* push_prio, int* push_rec) {
+  *next = S.nnext[it];                                   // (the iterator's increment: this node's slot is reused below)
+  *push_rec = -1;
+  const int t = it >> 1;
+  int c3;
+  const unsigned long long old_key = mn_ro_key(S.r1[t], S.r2[t]);
+  if (S.r1[t] == b) c3 = S.r2[t]; else c3 = S.r1[t];
+  const int lo = a < c3 ? a : c3, hi = a < c3 ? c3 : a;
+  const unsigned long long new_key = mn_ro_key(lo, hi);
+  const int n3 = mn_ro_erase(S, c3, old_key);
+  if (n3 == MN_RO_NULL) return MN_RO_CORRUPT;
+  int prev;
+  const int hit = mn_ro_find(S, a, new_key, &prev);
+  int mc;
+  if (hit != MN_RO_NULL) {
+    const int u = hit >> 1;
+    S.oml[u] += S.oml[t];
+    S.prio[t] = 1.17549435e-38f;                         // numeric_limits<float>::min(): never equals a queue entry
+    S.r1[t] = lo; S.r2[t] = hi;                          // (the folded record keeps two live ends, segment.cc:658-663)
+    S.prio[u] = mn_ro_score(S, u, &mc);
+    if (S.prio[u] >= 0.0f) { *push_prio = S.prio[u]; *push_rec = u; }
+  } else {
+    S.r1[t] = lo; S.r2[t] = hi;
+    if (!mn_ro_insert(S, a, it, new_key)) return MN_RO_ARENA_FULL;         // the slot b's map held
+    if (!mn_ro_insert(S, c3, n3, new_key)) return MN_RO_ARENA_FULL;
+    S.prio[t] = mn_ro_score(S, t, &mc);
+    if (S.prio[t] >= 0.0f) { *push_prio = S.prio[t]; *push_rec = t; }
   }
+  return MN_RO_RUNNING;
+}
+
+MN_REF_HD void mn_ro_merge_end(RoState& S, int r, int a, int b) {
   S.head[b] = MN_RO_NULL; S.nelem[b] = 0;
   S.parent[b] = a;
   S.r2[r] = -1;
   S.ctl[4]++;
+}
+
+MN_REF_HD int mn_ro_merge(RoState& S, int r, int mcls) {
+  int a, b, it;
+  int rc = mn_ro_merge_begin(S, r, mcls, &a, &b, &it);
+  if (rc != MN_RO_RUNNING) return rc;
+  while (it != MN_RO_NULL) {
+    int nx, prec; float pp;
+    rc = mn_ro_merge_node(S, a, b, it, &nx, &pp, &prec);
+    if (rc != MN_RO_RUNNING) return rc;
+    if (prec >= 0 && !mn_ro_push(S, pp, prec)) return MN_RO_HEAP_FULL;
+    it = nx;
+  }
+  mn_ro_merge_end(S, r, a, b);
   return MN_RO_RUNNING;
 }
 

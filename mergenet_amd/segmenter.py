@@ -36,7 +36,7 @@ MN_DEBUG_LEAN_EVENTS, MN_DEBUG_REPLAY = 16, 32
 MN_DEBUG_CLUSTERS = 512           # general rounds: contract order-free clusters of objects (opt-in)
 MN_DEBUG_OLD_EXACT = 256          # MN_MODE_EXACT by the small-list finisher instead of the exact engine
 MN_PROVE_ALWAYS, MN_PROVE_BY_MODE, MN_PROVE_NEVER = 1, 0, -1   # mn_options.require_proof
-MN_TIES_LOWEST_ID, MN_TIES_REFERENCE = 0, 1                    # mn_options.tie_order
+MN_TIES_DEFAULT, MN_TIES_REFERENCE, MN_TIES_LOWEST_ID = 0, 1, 2   # mn_options.tie_order
 MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
 
 SegmenterOptions = namedtuple("SegmenterOptions",
@@ -68,10 +68,11 @@ class MnStats(ctypes.Structure):
                 ("ms_output", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
                 ("ms_cc_edges", ctypes.c_float), ("ms_cc_cross", ctypes.c_float),
-                ("proof", ctypes.c_int), ("cores_condemned", ctypes.c_int), ("tied_steps", ctypes.c_int), ("tied_merges", ctypes.c_int)]
+                ("proof", ctypes.c_int), ("cores_condemned", ctypes.c_int), ("tied_steps", ctypes.c_int), ("tied_merges", ctypes.c_int),
+                ("tie_order_used", ctypes.c_int), ("reserved_i", ctypes.c_int)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}
 
 
 _f32p = ctypes.POINTER(ctypes.c_float)

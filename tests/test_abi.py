@@ -35,7 +35,7 @@ def test_option_struct_layout_matches_header():
     assert abs(o.merge_logprob_bias - 0.03) < 1e-7 and o.object_merge_factor == 1.0
     assert o.variant == seg.MN_VARIANT_CSEGMENT and o.prune_threshold == 200.0
     assert ctypes.sizeof(seg.MnOptions) == 17 * 4      # + tie_order
-    assert ctypes.sizeof(seg.MnStats) == 10 * 4 + 2 * 8 + 8 + 10 * 4 + 4 * 4   # + proof, cores_condemned, tied_steps, tied_merges
+    assert ctypes.sizeof(seg.MnStats) == 10 * 4 + 2 * 8 + 8 + 10 * 4 + 6 * 4   # + proof, cores_condemned, tied_steps, tied_merges, tie_order_used, reserved
 
 
 def test_binding_rejects_bad_buffers_like_the_reference_binding():

@@ -76,29 +76,86 @@ def test_exact_engine_equals_the_reference_on_every_vector(oracle, name):
     assert st["merges"] == g["spec"]["H"] * g["spec"]["W"] - st["num_objects"]
 
 
-@pytest.mark.xfail(strict=True, reason="the one documented difference of the exact engine: the ORDER among bit-equal "
-                   "priorities.  A radius-4 blur carries the out-of-image sameness value 1.0 into the maps near the "
-                   "image border, where it is clipped to 0.99, so the queue starts with runs of equal keys; the "
-                   "reference pops them in the order its std::priority_queue's heap mechanics and unordered_map "
-                   "iteration produce (segment.h:237-242, segment.cc:650-652), the engine by lowest record id.  The "
-                   "CPU model of the reference's semantics WITH the engine's rule gives the engine's event count "
-                   "exactly (DESIGN.md section 5), i.e. the difference is the tie rule and nothing else.")
+# ---- the order among bit-equal priorities ----------------------------------------------------------------
 @pytest.mark.parametrize("name", TIE_DECIDED)
-def test_exact_engine_on_inputs_decided_by_tie_order(oracle, name):
+def test_default_reproduces_the_reference_where_tie_order_decides(oracle, name):
+    """A radius-4 blur carries the out-of-image sameness value 1.0 into the maps near the image border, where it
+    is clipped to 0.99: the queue starts with runs of equal keys, and WHICH of them goes first decides instance
+    borders.  The reference pops them as its std::priority_queue's heap and its unordered_map's iteration order
+    produce (segment.h:237-242, 270-275; segment.cc:650-652).  MN_TIES_DEFAULT: the exact engine meets tied pops
+    (stats.tied_steps), the image is small enough, so it is redone by the reference-order loop (mn_reforder.h:
+    that heap and that hash map restated) -- and equals the reference's own output."""
     g = gu.load(name)
     mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    assert st["tie_order_used"] == seg.MN_TIES_REFERENCE and st["tied_steps"] > 0 and st["proof"] == seg.MN_PROOF_SEQUENTIAL
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+    mask, classes, part, st = _run(g, seg.MN_MODE_AUTO)
+    assert st["tie_order_used"] == seg.MN_TIES_REFERENCE
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+@pytest.mark.xfail(strict=True, reason="the exact engine's OWN tie rule (lowest record id first: MN_TIES_LOWEST_ID, and "
+                   "what images above MN_TIE_LIMIT_RECORDS get) differs from the reference on these inputs; the CPU model "
+                   "of the reference's semantics with that rule gives the engine's event count exactly (DESIGN.md section "
+                   "5): the difference is the tie rule and nothing else")
+@pytest.mark.parametrize("name", TIE_DECIDED)
+def test_lowest_id_tie_rule_on_inputs_decided_by_tie_order(oracle, name):
+    g = gu.load(name)
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
 
 
 @pytest.mark.parametrize("name", TIE_DECIDED)
-def test_exact_engine_stays_close_where_tie_order_decides(oracle, name):
+def test_lowest_id_tie_rule_stays_close_where_tie_order_decides(oracle, name):
     """... and a floor under it: the partitions agree on at least 98.5 % of the pixels (measured 98.9-99.99 %
     on eight such images, tests/tools/gpu_exact_campaign.py) and differ by at most one instance."""
     from mergenet_amd import labels
     g = gu.load(name)
-    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
+    assert st["tie_order_used"] == seg.MN_TIES_LOWEST_ID
     assert abs(len(classes) - len(g["object_class"])) <= 1
     assert labels.agreement(mask, g["mask"]) >= 0.985 * mask.size, st
+
+
+@pytest.mark.parametrize("name", ["cseg_adv_48x48_o0", "cseg_synth_32x64_n60", "cseg_checker_96x128_b015",
+                                  "cseg_blur_64x128_r2", "cseg_synth_48x80_c81", "cseg_adv_16x16_o2"])
+def test_reference_order_loop_pops_what_the_reference_pops(oracle, name):
+    """MN_TIES_REFERENCE: the same partition AND the same number of pops as the oracle's run of the reference's
+    loop on std::priority_queue / std::unordered_map -- stale queue entries included, so the queue itself went
+    through the same states (with other sameness biases and 81 classes among the cases)."""
+    g = gu.load(name)
+    ref = oracle.run_csegment(g["class_probs"], g["sameness_probs"], g["spec"]["C"], g["offsets"], *g["spec"]["opts"])
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_REFERENCE)
+    assert st["tie_order_used"] == seg.MN_TIES_REFERENCE
+    assert oracle.same_partition(part, ref.partition), name
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+    assert st["finisher_steps"] == ref.stats["n_pops"], (st["finisher_steps"], ref.stats["n_pops"])
+    assert st["merges"] == ref.stats["n_merges"]
+    assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+
+
+def test_reference_order_loop_across_launches_and_with_a_small_workspace(oracle, monkeypatch, capfd):
+    """The loop's state lives in memory: a launch that has used up its pop budget is followed by another
+    (MN_X_BUDGET); a run that fills the bucket arena or the queue is repeated with twice as much."""
+    g = gu.load("cseg_synth_32x64_n35")
+    monkeypatch.setenv("MN_X_BUDGET", "3000")
+    monkeypatch.setenv("MN_RO_ARENA_PER_PIXEL", "8")
+    monkeypatch.setenv("MN_RO_HEAP_PER_RECORD", "1")
+    monkeypatch.setenv("MN_TRACE_EXACT", "1")
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_REFERENCE)
+    err = capfd.readouterr().err
+    assert "status 3" in err and "status 1" in err          # (arena full, workspace doubled, ... done)
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_tie_limit_keeps_large_images_with_the_exact_engine(oracle, monkeypatch):
+    """MN_TIES_DEFAULT redoes an image with tied pops only up to MN_TIE_LIMIT_RECORDS initial records (the
+    reference-order loop is sequential); above, the exact engine's answer stands and the statistics say so."""
+    monkeypatch.setenv("MN_TIE_LIMIT", "1000")
+    g = gu.load("cseg_synth_32x64_n35")
+    mask, classes, part, st = _run(g, seg.MN_MODE_EXACT)
+    assert st["tie_order_used"] == seg.MN_TIES_LOWEST_ID and st["tied_steps"] > 0
+    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
 
 
 def test_exact_engine_blurred_256x512_within_ten_seconds(oracle):
@@ -138,9 +195,9 @@ def test_exact_engine_relaunch_after_a_step_budget(oracle, monkeypatch):
     """The loop kernel comes back when its step budget is used up and is launched again (block maxima
     rebuilt from the leaves): the result must not depend on where it was cut."""
     g = gu.load("cseg_blur_64x128_r2")
-    a = _run(g, seg.MN_MODE_EXACT)
+    a = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
     monkeypatch.setenv("MN_X_BUDGET", "777")
-    b = _run(g, seg.MN_MODE_EXACT)
+    b = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
     assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
     assert a[3]["finisher_steps"] == b[3]["finisher_steps"]
     assert oracle.masks_equivalent(b[0], b[1], g["mask"], g["object_class"])
@@ -260,7 +317,8 @@ def test_tied_pops_are_counted():
     (unclipped, network-like) values give none or a handful; the clipped generator's plateaus give thousands."""
     adv = _run(gu.load("cseg_adv_64x64_o0"), seg.MN_MODE_EXACT)[3]
     assert adv["tied_steps"] <= 4 and adv["tied_merges"] <= adv["tied_steps"]
-    syn = _run(gu.load("cseg_synth_64x128_n60"), seg.MN_MODE_EXACT)[3]
+    syn = _run(gu.load("cseg_synth_64x128_n60"), seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)[3]
     assert syn["tied_steps"] > 1000 and 0 < syn["tied_merges"] <= syn["tied_steps"]
+    assert syn["tie_order_used"] == seg.MN_TIES_LOWEST_ID
     fast = _run(gu.load("cseg_synth_64x128_n15"), seg.MN_MODE_COMPONENTS, require_proof=-1)[3]
     assert fast["tied_steps"] == 0 and fast["tied_merges"] == 0

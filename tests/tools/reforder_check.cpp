@@ -1,9 +1,9 @@
 // Host build of mergenet_amd/csrc/mn_reforder.h (TEST HARNESS: the product runs the same text on the GPU).
 //   g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off tests/tools/reforder_check.cpp -o tests/tools/libreforder_host.so
 // Exports:
-//   reforder_containers_check(seed, ops)  the flat-array hash map and heap against std::unordered_map and
+//   reforder_containers_check(seed, ops, every)  the flat-array hash map and heap against std::unordered_map and
 //                                         std::priority_queue, operation by operation: iteration order of the map
-//                                         after every step, top of the heap after every push / pop.  0 = equal.
+//                                         after every `every`-th step, top of the heap after every push / pop.  0 = equal.
 //   reforder_host_run(...)                the whole merge of one image with the reference's arithmetic (glibc logf,
 //                                         double log for log(1 - p)); writes the partition (survivor per pixel).
 #include <math.h>
@@ -32,7 +32,7 @@ struct Owned {
     head.assign(N, MN_RO_NULL); single.assign(N, MN_RO_NULL); boff.assign(N, 0); barena.assign(arena, MN_RO_NULL);
     nnext.assign(2 * NL, MN_RO_NULL); nkey.assign(2 * NL, 0);
     r1.assign(NL, -1); r2.assign(NL, -1); oml.assign(NL, 0.0f); prio.assign(NL, -1.0f);
-    hprio.assign(hcap, 0.0f); hrec.assign(hcap, 0); lp.assign((size_t)N * C, 0.0f); ctl.assign(8, 0);
+    hprio.assign(hcap, 0.0f); hrec.assign(hcap, 0); lp.assign((size_t)N * C, 0.0f); ctl.assign(16, 0);
     for (int i = 0; i < N; i++) parent[i] = i;
     S.N = N; S.C = C; S.NL = NL; S.omf = 1.0f; S.bias = 0.0f;
     S.osize = osize.data(); S.ocls = ocls.data(); S.lp = lp.data(); S.parent = parent.data();
@@ -59,7 +59,8 @@ uint64_t rng() {
 
 }  // namespace
 
-extern "C" int reforder_containers_check(unsigned long long seed, int ops) {
+extern "C" int reforder_containers_check(unsigned long long seed, int ops, int every) {
+  if (every < 1) every = 1;
   rng_state = seed;
   // --- the hash map: ONE object's map, keys of the form the reference uses, random inserts / erases ---
   {
@@ -90,6 +91,7 @@ extern "C" int reforder_containers_check(unsigned long long seed, int ops) {
         ref.erase((size_t)key);
       }
       if ((long long)ref.bucket_count() != (long long)W.S.bcount[0]) return 2000000 + step;
+      if (step % every != 0 && step != ops - 1) continue;          // (the full walk is O(size))
       int n = W.S.head[0];
       for (std::unordered_map<size_t, int>::iterator it = ref.begin(); it != ref.end(); ++it) {
         if (n == MN_RO_NULL || n != it->second || W.S.nkey[n] != (unsigned long long)it->first) return 3000000 + step;
