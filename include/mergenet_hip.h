@@ -169,8 +169,8 @@ typedef struct mn_stats {
                                   only; an approximation of the sequential order on order-dependent
                                   inputs), 1 = certificate (ANY order of the lazy greedy ends here,
                                   DESIGN.md section 5), 2 = the sequential order itself was run
-                                  (MN_MODE_EXACT; ties between bit-equal priorities go to the lowest
-                                  record id, which agrees with the reference on every vector held)   */
+                                  (MN_MODE_EXACT; among bit-equal priorities see tie_order / tie_order_used /
+                                  tied_steps)                                                         */
   int cores_condemned;         /* general rounds: 1 if a core held an edge that was not positive and
                                   fell apart again (mn_core_check); 0 otherwise                    */
   int tied_steps;              /* MN_MODE_EXACT: pops at which a second live record held the bit-equal stored
