@@ -1240,7 +1240,7 @@ static int r_ensure(mn_context* c, int N, int O, int C) {
                  o_single = take((size_t)N * 4), o_barena = take((size_t)arena_cap * 4),
                  o_nnext = take((size_t)NL * 2 * 4), o_nkey = take((size_t)NL * 2 * 8), o_r1 = take((size_t)NL * 4),
                  o_r2 = take((size_t)NL * 4), o_oml = take((size_t)NL * 4), o_prio = take((size_t)NL * 4),
-                 o_hprio = take((size_t)heap_cap * 4), o_hrec = take((size_t)heap_cap * 4), o_ctl = take(128);
+                 o_heap = take((size_t)heap_cap * 8), o_ctl = take(128);
     MN_HIP(hipMalloc(&w.block, off));
     MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), 128));
     w.bytes = off;
@@ -1254,7 +1254,7 @@ static int r_ensure(mn_context* c, int N, int O, int C) {
     S.nnext = reinterpret_cast<int*>(b + o_nnext); S.nkey = reinterpret_cast<unsigned long long*>(b + o_nkey);
     S.r1 = reinterpret_cast<int*>(b + o_r1); S.r2 = reinterpret_cast<int*>(b + o_r2);
     S.oml = reinterpret_cast<float*>(b + o_oml); S.prio = reinterpret_cast<float*>(b + o_prio);
-    S.hprio = reinterpret_cast<float*>(b + o_hprio); S.hrec = reinterpret_cast<int*>(b + o_hrec);
+    S.heap = reinterpret_cast<unsigned long long*>(b + o_heap);
     S.ctl = reinterpret_cast<long long*>(b + o_ctl);
     w.n_pix = N; w.n_rec = NL; w.n_cls = C; w.arena_cap = arena_cap; w.heap_cap = heap_cap;
   }

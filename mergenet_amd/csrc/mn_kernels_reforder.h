@@ -38,42 +38,51 @@ __device__ __forceinline__ void mn_ro_wave_pushup(const RoState& S, long long ho
   // lane l: the ancestor at distance l + 1 of the hole (1-based index (hole + 1) >> (l + 1))
   const long long j = lane < 48 ? ((hole + 1) >> (lane + 1)) : 0;
   const bool valid = j >= 1;
-  float ap = 0.0f;
-  int ar = 0;
-  if (valid) { ap = S.hprio[j - 1]; ar = S.hrec[j - 1]; }
-  const unsigned long long movers = __ballot(valid && ap < pr);      // __push_heap: while (parent < value)
+  unsigned long long ae = 0ull;
+  if (valid) ae = S.heap[j - 1];
+  const unsigned long long movers = __ballot(valid && mn_ro_entry_prio(ae) < pr);      // __push_heap: while (parent < value)
   const int k = (~movers == 0ull) ? 64 : (__ffsll((long long)~movers) - 1);   // the first ancestor that stays
   if (lane < k) {
     const long long dest = ((hole + 1) >> lane) - 1;
-    S.hprio[dest] = ap; S.hrec[dest] = ar;
+    S.heap[dest] = ae;
   }
   if (lane == 0) {
     const long long dest = ((hole + 1) >> k) - 1;
-    S.hprio[dest] = pr; S.hrec[dest] = rec;
+    S.heap[dest] = mn_ro_entry(pr, rec);
   }
 }
 
-__device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, float* pr_out, int* rec_out, int lane) {
-  // top and last entry in one round trip
-  float tp = 0.0f; int tr = 0;
-  if (lane == 0) { tp = S.hprio[0]; tr = S.hrec[0]; }
-  if (lane == 1) { tp = S.hprio[n - 1]; tr = S.hrec[n - 1]; }
-  *pr_out = __shfl(tp, 0); *rec_out = __shfl(tr, 0);
-  const float vp = __shfl(tp, 1);
-  const int vr = __shfl(tr, 1);
+// pop: returns the top entry and, fetched while the hole travels down, the popped record's stored priority and
+// second end (what the caller's stale test reads)
+__device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, float* pr_out, int* rec_out,
+                                               float* rec_prio, int* rec_r2, int lane) {
+  // ONE round trip: the top (lane 62), the last entry (lane 63) and the 62 descendants of the root over five levels
   const long long len = n - 1;
+  const int d = 31 - __clz(lane + 2);                    // lane l < 62: level d = floor(log2(l + 2)) (1..5) ...
+  const int jl = (lane + 2) - (1 << d);                  // ... position jl in it
+  float p = 0.0f; int rr = 0;
+  {
+    const long long idx0 = lane < 62 ? (long long)lane + 1 : (lane == 62 ? 0 : len);
+    if (idx0 < n) { const unsigned long long e = S.heap[idx0]; p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
+  }
+  *pr_out = __shfl(p, 62); *rec_out = __shfl(rr, 62);
+  const float vp = __shfl(p, 63);
+  const int vr = __shfl(rr, 63);
+  *rec_prio = S.prio[*rec_out];                          // (uniform loads, in flight while the hole goes down)
+  *rec_r2 = S.r2[*rec_out];
   n = len;
   if (len == 0) return;
   const long long half = (len - 1) / 2;
   long long hole = 0;
-  // lane l < 62: descendant at level d = floor(log2(l + 2)) (1..5), position j in its level
-  const int d = 31 - __clz(lane + 2);
-  const int jl = (lane + 2) - (1 << d);
+  bool fetched = true;
   while (hole < half) {                                  // __adjust_heap: to the bottom along the larger children
-    const long long idx = (((hole + 1) << d) + jl) - 1;
-    const bool valid = lane < 62 && idx < len;
-    float p = 0.0f; int rr = 0;
-    if (valid) { p = S.hprio[idx]; rr = S.hrec[idx]; }
+    if (!fetched) {
+      const long long idx = (((hole + 1) << d) + jl) - 1;
+      const bool valid = lane < 62 && idx < len;
+      p = 0.0f; rr = 0;
+      if (valid) { const unsigned long long e = S.heap[idx]; p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
+    }
+    fetched = false;
     long long cur = hole;
     int curj = 0;
 #pragma unroll
@@ -82,7 +91,7 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
         const int lr = (1 << lev) - 2 + 2 * curj + 1, ll = lr - 1;
         const float pR = __shfl(p, lr), pL = __shfl(p, ll);
         const int chosen = (pR < pL) ? ll : lr;          // the right child among equals
-        if (lane == chosen) { S.hprio[cur] = p; S.hrec[cur] = rr; }
+        if (lane == chosen) S.heap[cur] = mn_ro_entry(p, rr);
         curj = chosen - ((1 << lev) - 2);
         cur = (((hole + 1) << lev) + curj) - 1;
       }
@@ -91,7 +100,7 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
   }
   if ((len & 1) == 0 && hole == (len - 2) / 2) {         // a last node with a left child only
     const long long child = 2 * hole + 1;
-    if (lane == 0) { S.hprio[hole] = S.hprio[child]; S.hrec[hole] = S.hrec[child]; }
+    if (lane == 0) S.heap[hole] = S.heap[child];
     hole = child;
   }
   mn_ro_wave_pushup(S, hole, vp, vr, lane);              // ... and back up with the last entry's value
@@ -100,12 +109,19 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
 // ONE wave: lane 0 runs the maps and the records (mn_reforder.h), the wave the queue.  Comes back when `budget`
 // pops (4 x budget records of the constructor's loop) are used up: the state is in memory, the next launch goes on.
 __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long budget) {
+  __shared__ int s_nodes[66];                            // the records of a walk (64), their count, the next node
   const int lane = threadIdx.x;
   const long long st0 = S.ctl[0];
   if (st0 != MN_RO_RUNNING && st0 != MN_RO_BUDGET) return;
   long long n = S.ctl[1], biggest = S.ctl[6], pops = 0;
   int status = MN_RO_RUNNING;
-  long long t_init = 0, t_pop = 0, t_merge = 0, t_mark = wall_clock64();   // (100 MHz; MN_TRACE_EXACT prints them)
+#ifdef MN_RO_STAMPS
+#define MN_RO_STAMP(acc) { const long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; }
+#else
+#define MN_RO_STAMP(acc)
+#endif
+  long long t_init = 0, t_pop = 0, t_merge = 0, t_mark = 0;    // (-DMN_RO_STAMPS: 100 MHz ticks per phase, MN_TRACE_EXACT prints them)
+  (void)t_mark;
   // ---- the constructor's loop (segment.cc:209-231) ----
   long long r = S.ctl[5];
   if (r < S.NL) {
@@ -126,41 +142,72 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
       }
     }
     if (lane == 0) S.ctl[5] = r;
-    { const long long t = wall_clock64(); t_init += t - t_mark; t_mark = t; }
+    MN_RO_STAMP(t_init)
   }
   // ---- RunSegmentation (segment.cc:539-573) ----
   if (status == MN_RO_RUNNING && r >= S.NL) {
     status = MN_RO_DONE;
     while (n > 0) {
       if (pops >= budget) { status = MN_RO_BUDGET; break; }
-      float q; int rec;
-      mn_ro_wave_pop(S, n, &q, &rec, lane);
+      float q, stored; int rec, second;
+      mn_ro_wave_pop(S, n, &q, &rec, &stored, &second, lane);
       pops++;
-      { const long long t = wall_clock64(); t_pop += t - t_mark; t_mark = t; }
-      if (q != S.prio[rec]) continue;                     // a stale entry (uniform: every lane reads the same word)
-      if (S.r2[rec] < 0) continue;
+      MN_RO_STAMP(t_pop)
+      if (q != stored) continue;                          // a stale entry (segment.cc:554)
+      if (second < 0) continue;                           // a merged record (segment.cc:557)
       float f = 0.0f; int mc = 0;
       if (lane == 0) { f = mn_ro_score(S, rec, &mc); S.prio[rec] = f; }
       f = __shfl(f, 0);
       if (f == q) {
         int a = 0, b = 0, it = MN_RO_NULL, rc = MN_RO_RUNNING;
         if (lane == 0) rc = mn_ro_merge_begin(S, rec, mc, &a, &b, &it);
-        rc = __shfl(rc, 0); it = __shfl(it, 0);
+        rc = __shfl(rc, 0); it = __shfl(it, 0); a = __shfl(a, 0); b = __shfl(b, 0);
+        // The walk over the absorbed object's records, up to 64 at a time: lane 0 follows the list (the
+        // iteration order of the reference's unordered_map), then every lane takes ONE record -- out of the
+        // third object's map, look-up in the survivor's, fold or re-key, into the third object's map, fresh
+        // priority: no two records of a walk share a third object -- then, IN LIST ORDER, lane 0 puts the
+        // adopted ones into the survivor's map and the wave pushes the fresh priorities.
         while (rc == MN_RO_RUNNING && it != MN_RO_NULL) {
-          int nx = MN_RO_NULL, prec = -1; float pp = 0.0f;
-          if (lane == 0) rc = mn_ro_merge_node(S, a, b, it, &nx, &pp, &prec);
-          rc = __shfl(rc, 0); nx = __shfl(nx, 0); prec = __shfl(prec, 0); pp = __shfl(pp, 0);
-          if (rc == MN_RO_RUNNING && prec >= 0) {
-            if (n >= S.hcap) { rc = MN_RO_HEAP_FULL; break; }
-            mn_ro_wave_pushup(S, n, pp, prec, lane);
-            n++;
-            biggest = n > biggest ? n : biggest;
+          if (lane == 0) {
+            int x = it, cnt = 0;
+            while (x != MN_RO_NULL && cnt < 64) { s_nodes[cnt++] = x; x = S.nnext[x]; }
+            s_nodes[64] = cnt; s_nodes[65] = x;
           }
-          it = nx;
+          __syncthreads();
+          const int cnt = s_nodes[64];
+          it = s_nodes[65];
+          const int node = lane < cnt ? s_nodes[lane] : MN_RO_NULL;
+          __syncthreads();
+          int nx, prec = -1, myrc = MN_RO_RUNNING;
+          float pp = 0.0f;
+          unsigned long long akey = 0ull;
+          if (node != MN_RO_NULL) myrc = mn_ro_merge_node(S, a, b, node, &nx, &pp, &prec, 1, &akey);
+          const unsigned long long failed = __ballot(myrc != MN_RO_RUNNING);
+          if (failed) { rc = __shfl(myrc, __ffsll((long long)failed) - 1); break; }
+          for (int i = 0; i < cnt && rc == MN_RO_RUNNING; i++) {          // (uniform)
+            const unsigned klo = (unsigned)__shfl((int)(akey & 0xFFFFFFFFull), i), khi = (unsigned)__shfl((int)(akey >> 32), i);
+            const int nd = __shfl(node, i);
+            const unsigned long long k = ((unsigned long long)khi << 32) | klo;
+            if (k != 0ull) {
+              int ok = 1;
+              if (lane == 0) ok = mn_ro_insert(S, a, nd, k) ? 1 : 0;
+              if (!__shfl(ok, 0)) rc = MN_RO_ARENA_FULL;
+            }
+          }
+          for (int i = 0; i < cnt && rc == MN_RO_RUNNING; i++) {
+            const int pr_rec = __shfl(prec, i);
+            const float pr_val = __shfl(pp, i);
+            if (pr_rec >= 0) {
+              if (n >= S.hcap) { rc = MN_RO_HEAP_FULL; break; }
+              mn_ro_wave_pushup(S, n, pr_val, pr_rec, lane);
+              n++;
+              biggest = n > biggest ? n : biggest;
+            }
+          }
         }
         if (rc != MN_RO_RUNNING) { status = rc; break; }
         if (lane == 0) mn_ro_merge_end(S, rec, a, b);
-        { const long long t = wall_clock64(); t_merge += t - t_mark; t_mark = t; }
+        MN_RO_STAMP(t_merge)
       } else if (f >= 0.0f) {
         if (n >= S.hcap) { status = MN_RO_HEAP_FULL; break; }
         mn_ro_wave_pushup(S, n, f, rec, lane);

@@ -54,7 +54,7 @@ struct RoState {
   int* r1; int* r2;                // ends, r1 < r2 by id; r2 = -1: merged away (obj2 = NULL, segment.cc:726)
   float* oml; float* prio;
   // the queue (segmenter_queue)
-  float* hprio; int* hrec; long long hcap;
+  unsigned long long* heap; long long hcap;     // entry = (record << 32) | bits of the float priority: ONE access
   // progress (kept in memory so that a launch can stop and the next one go on)
   long long* ctl;                  // [0] status, [1] heap size, [2] arena bump, [3] pops, [4] merges, [5] init cursor, [6] largest heap size
 };
@@ -68,6 +68,18 @@ MN_REF_HD long long mn_ro_next_bcount(long long bc) {
     if (chain[i] == bc) return chain[i + 1];
   return -1;
 }
+
+MN_REF_HD unsigned long long mn_ro_entry(float pr, int rec) {
+  union { float f; unsigned u; } c;
+  c.f = pr;
+  return ((unsigned long long)(unsigned)rec << 32) | (unsigned long long)c.u;
+}
+MN_REF_HD float mn_ro_entry_prio(unsigned long long e) {
+  union { float f; unsigned u; } c;
+  c.u = (unsigned)(e & 0xFFFFFFFFull);
+  return c.f;
+}
+MN_REF_HD int mn_ro_entry_rec(unsigned long long e) { return (int)(e >> 32); }
 
 MN_REF_HD int* mn_ro_buckets(const RoState& S, int o) {
   return S.bcount[o] == 1 ? &S.single[o] : S.barena + S.boff[o];
@@ -97,10 +109,16 @@ MN_REF_HD int mn_ro_find(const RoState& S, int o, unsigned long long key, int* p
 // _M_rehash_aux (unique keys): every node, in list order, goes to the front of its new bucket; a bucket
 // seen for the first time goes to the front of the whole list
 MN_REF_HD bool mn_ro_rehash(RoState& S, int o, long long nbc) {
-  long long bump = S.ctl[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (several lanes may grow different objects' maps at once: where an array lands does not matter)
+  const long long bump = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(&S.ctl[2]), (unsigned long long)nbc);
   if (bump + nbc > S.barena_cap) return false;
-  int* nb = S.barena + bump;
+#else
+  const long long bump = S.ctl[2];
+  if (bump + nbc > S.barena_cap) return false;
   S.ctl[2] = bump + nbc;
+#endif
+  int* nb = S.barena + bump;
   for (long long i = 0; i < nbc; i++) nb[i] = MN_RO_NULL;
   int p = S.head[o];
   int first = MN_RO_NULL;                               // before_begin.next
@@ -187,11 +205,12 @@ MN_REF_HD bool mn_ro_push(RoState& S, float pr, int rec) {
   if (hole + 1 > S.ctl[6]) S.ctl[6] = hole + 1;        // (largest queue so far)
   while (hole > 0) {
     const long long par = (hole - 1) / 2;
-    if (!(S.hprio[par] < pr)) break;
-    S.hprio[hole] = S.hprio[par]; S.hrec[hole] = S.hrec[par];
+    const unsigned long long e = S.heap[par];
+    if (!(mn_ro_entry_prio(e) < pr)) break;
+    S.heap[hole] = e;
     hole = par;
   }
-  S.hprio[hole] = pr; S.hrec[hole] = rec;
+  S.heap[hole] = mn_ro_entry(pr, rec);
   return true;
 }
 
@@ -199,30 +218,32 @@ MN_REF_HD bool mn_ro_push(RoState& S, float pr, int rec) {
 // along the larger children -- the RIGHT one among equals -- then back up with __push_heap)
 MN_REF_HD void mn_ro_pop(RoState& S, float* pr_out, int* rec_out) {
   const long long n = S.ctl[1];
-  *pr_out = S.hprio[0]; *rec_out = S.hrec[0];
+  *pr_out = mn_ro_entry_prio(S.heap[0]); *rec_out = mn_ro_entry_rec(S.heap[0]);
   const long long len = n - 1;
   S.ctl[1] = len;
   if (len == 0) return;
-  const float vp = S.hprio[len]; const int vr = S.hrec[len];
+  const unsigned long long v = S.heap[len];
+  const float vp = mn_ro_entry_prio(v);
   long long hole = 0, child = 0;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (S.hprio[child] < S.hprio[child - 1]) child--;
-    S.hprio[hole] = S.hprio[child]; S.hrec[hole] = S.hrec[child];
+    if (mn_ro_entry_prio(S.heap[child]) < mn_ro_entry_prio(S.heap[child - 1])) child--;
+    S.heap[hole] = S.heap[child];
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    S.hprio[hole] = S.hprio[child - 1]; S.hrec[hole] = S.hrec[child - 1];
+    S.heap[hole] = S.heap[child - 1];
     hole = child - 1;
   }
   while (hole > 0) {
     const long long par = (hole - 1) / 2;
-    if (!(S.hprio[par] < vp)) break;
-    S.hprio[hole] = S.hprio[par]; S.hrec[hole] = S.hrec[par];
+    const unsigned long long e = S.heap[par];
+    if (!(mn_ro_entry_prio(e) < vp)) break;
+    S.heap[hole] = e;
     hole = par;
   }
-  S.hprio[hole] = vp; S.hrec[hole] = vr;
+  S.heap[hole] = v;
 }
 
 // ComputeClassDeltaLogprob + UpdateMergePriority (segment.cc:107-150), the reference's float32 operation order
@@ -289,9 +310,14 @@ MN_REF_HD int mn_ro_merge_begin(RoState& S, int r, int mcls, int* a_out, int* b_
   return MN_RO_RUNNING;
 }
 
-MN_REF_HD int mn_ro_merge_node(RoState& S, int a, int b, int it, int* next, float* push_prio, int* push_rec) {
+// `defer_a` (device: the records of a walk go to one lane each): the insert into the SURVIVOR's map -- the one
+// step whose order among the records of a walk matters -- is left to the caller (*adopt_key != 0).  Everything
+// else touches the record itself and the third object's map, which no other record of this walk touches.
+MN_REF_HD int mn_ro_merge_node(RoState& S, int a, int b, int it, int* next, float* push_prio, int* push_rec,
+                               int defer_a = 0, unsigned long long* adopt_key = 0) {
   *next = S.nnext[it];                                   // (the iterator's increment: this node's slot is reused below)
   *push_rec = -1;
+  if (adopt_key) *adopt_key = 0ull;
   const int t = it >> 1;
   int c3;
   const unsigned long long old_key = mn_ro_key(S.r1[t], S.r2[t]);
@@ -312,7 +338,8 @@ MN_REF_HD int mn_ro_merge_node(RoState& S, int a, int b, int it, int* next, floa
     if (S.prio[u] >= 0.0f) { *push_prio = S.prio[u]; *push_rec = u; }
   } else {
     S.r1[t] = lo; S.r2[t] = hi;
-    if (!mn_ro_insert(S, a, it, new_key)) return MN_RO_ARENA_FULL;         // the slot b's map held
+    if (defer_a) *adopt_key = new_key;                                     // (keys are never 0: hi >= 1)
+    else if (!mn_ro_insert(S, a, it, new_key)) return MN_RO_ARENA_FULL;    // the slot b's map held
     if (!mn_ro_insert(S, c3, n3, new_key)) return MN_RO_ARENA_FULL;
     S.prio[t] = mn_ro_score(S, t, &mc);
     if (S.prio[t] >= 0.0f) { *push_prio = S.prio[t]; *push_rec = t; }

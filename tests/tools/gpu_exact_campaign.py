@@ -51,7 +51,7 @@ def oracle_one(job):
     family, seed = job
     s, offs, opts = make(family, seed)
     r = ck.run_csegment(s.class_probs, s.sameness_probs, s.class_probs.shape[0], offs, *opts)
-    return family, seed, r.mask, r.object_class, r.partition, r.total_logprob, r.stats["n_merges"], r.stats["n_live_pops"]
+    return family, seed, r.mask, r.object_class, r.partition, r.total_logprob, r.stats["n_merges"], (r.stats["n_live_pops"], r.stats["n_pops"])
 
 
 if __name__ == "__main__":
@@ -66,20 +66,25 @@ if __name__ == "__main__":
     print("oracle: %d images in %.1f s" % (len(jobs), time.time() - t0), flush=True)
     tally = {f: [0, 0, 0, 0, 0, 0] for f in fams}  # equal, same event count, total, images with tied pops, tied steps, tied merges
     bad = []
+    used = {}
     tg = 0.0
     for (family, seed, rmask, rcls, rpart, rlp, rmerges, rpops) in refs:
         s, offs, opts = make(family, seed)
         C, H, W = s.class_probs.shape
         ctx = seg.HostContext(H, W, C, len(offs))
         o = seg.default_options(same_different_bias=opts[0], object_merge_factor=opts[1],
-                                merge_logprob_bias=opts[2], mode=seg.MN_MODE_EXACT, clip_inputs=1)
+                                merge_logprob_bias=opts[2], mode=seg.MN_MODE_EXACT, clip_inputs=1,
+                                tie_order=int(os.environ.get("MN_TIES", seg.MN_TIES_LOWEST_ID)))
         t = time.time()
         mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
         tg += time.time() - t
         ctx.close()
         ok = ck.masks_equivalent(mask, classes, rmask, rcls) and ck.same_partition(part, rpart) and \
             abs(st["total_logprob"] - rlp) <= 1e-5 * abs(rlp) and st["merges"] == rmerges
-        ev = st["finisher_steps"] == rpops
+        ev = st["finisher_steps"] == rpops[1 if st["tie_order_used"] == seg.MN_TIES_REFERENCE else 0]
+        used[st["tie_order_used"]] = used.get(st["tie_order_used"], 0) + 1
+        print("  %-8s seed %d: %5.1f s, tie order used %d, tied steps %d, equal %s" % (
+            family, seed, time.time() - t, st["tie_order_used"], st["tied_steps"], ok), flush=True)
         tally[family][0] += int(ok); tally[family][1] += int(ev); tally[family][2] += 1
         tally[family][3] += int(st["tied_steps"] > 0); tally[family][4] += st["tied_steps"]; tally[family][5] += st["tied_merges"]
         if not ok:
@@ -88,8 +93,8 @@ if __name__ == "__main__":
             bad.append((family, seed, "instances %d vs %d" % (len(classes), len(rcls)), "pixels agreeing %.4f" % agree,
                         "tied steps %d merges %d" % (st["tied_steps"], st["tied_merges"])))
     for f in fams:
-        print("%-8s equal to the oracle %2d / %2d   same number of live pops %2d / %2d   images with tied pops %2d "
+        print("%-8s equal to the oracle %2d / %2d   same number of pops as the oracle %2d / %2d   images with tied pops %2d "
               "(tied steps %d, of which merges %d)" %
               (f, tally[f][0], tally[f][2], tally[f][1], tally[f][2], tally[f][3], tally[f][4], tally[f][5]))
-    print("exact engine: %.1f s for %d images; mismatching: %s" % (tg, len(jobs), bad))
+    print("exact engine: %.1f s for %d images (tie order used: %s); mismatching: %s" % (tg, len(jobs), used, bad))
     sys.exit(1 if bad else 0)

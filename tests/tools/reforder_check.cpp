@@ -23,16 +23,16 @@ namespace {
 
 struct Owned {
   RoState S;
-  std::vector<int> osize, ocls, parent, bcount, nelem, head, single, barena, nnext, r1, r2, hrec;
-  std::vector<float> lp, oml, prio, hprio;
+  std::vector<int> osize, ocls, parent, bcount, nelem, head, single, barena, nnext, r1, r2;
+  std::vector<float> lp, oml, prio;
   std::vector<long long> boff, ctl;
-  std::vector<unsigned long long> nkey;
+  std::vector<unsigned long long> nkey, heap;
   void alloc(int N, int C, long long NL, long long arena, long long hcap) {
     osize.assign(N, 1); ocls.assign(N, 0); parent.resize(N); bcount.assign(N, 1); nelem.assign(N, 0);
     head.assign(N, MN_RO_NULL); single.assign(N, MN_RO_NULL); boff.assign(N, 0); barena.assign(arena, MN_RO_NULL);
     nnext.assign(2 * NL, MN_RO_NULL); nkey.assign(2 * NL, 0);
     r1.assign(NL, -1); r2.assign(NL, -1); oml.assign(NL, 0.0f); prio.assign(NL, -1.0f);
-    hprio.assign(hcap, 0.0f); hrec.assign(hcap, 0); lp.assign((size_t)N * C, 0.0f); ctl.assign(16, 0);
+    heap.assign(hcap, 0ull); lp.assign((size_t)N * C, 0.0f); ctl.assign(16, 0);
     for (int i = 0; i < N; i++) parent[i] = i;
     S.N = N; S.C = C; S.NL = NL; S.omf = 1.0f; S.bias = 0.0f;
     S.osize = osize.data(); S.ocls = ocls.data(); S.lp = lp.data(); S.parent = parent.data();
@@ -40,7 +40,7 @@ struct Owned {
     S.single = single.data(); S.barena = barena.data(); S.barena_cap = arena;
     S.nnext = nnext.data(); S.nkey = nkey.data();
     S.r1 = r1.data(); S.r2 = r2.data(); S.oml = oml.data(); S.prio = prio.data();
-    S.hprio = hprio.data(); S.hrec = hrec.data(); S.hcap = hcap; S.ctl = ctl.data();
+    S.heap = heap.data(); S.hcap = hcap; S.ctl = ctl.data();
   }
 };
 
@@ -125,7 +125,7 @@ extern "C" int reforder_containers_check(unsigned long long seed, int ops, int e
         ref.pop();
       }
       if ((long long)ref.size() != W.S.ctl[1]) return 8000000 + step;
-      if (!ref.empty() && (W.S.hprio[0] != ref.top().first || W.S.hrec[0] != ref.top().second)) return 9000000 + step;
+      if (!ref.empty() && (mn_ro_entry_prio(W.S.heap[0]) != ref.top().first || mn_ro_entry_rec(W.S.heap[0]) != ref.top().second)) return 9000000 + step;
     }
   }
   return 0;
