@@ -1281,7 +1281,13 @@ static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
     S.lp = X.lp; S.parent = X.parent; S.omf = P.omf; S.bias = P.bias;
     hipLaunchKernelGGL(mn_ro_prepare_objects, dim3(grid_for((size_t)P.N, 256)), dim3(256), 0, st, P, X, S);
     hipLaunchKernelGGL(mn_ro_prepare_records, dim3(grid_for((size_t)S.NL, 256)), dim3(256), 0, st, P, X, S);
+    // (ctl[7]: lanes of the parallel map construction that found the bucket arena full)
+    hipLaunchKernelGGL(mn_ro_build_maps, dim3(grid_for((size_t)P.N, 64)), dim3(64), 0, st, P, S,
+                       reinterpret_cast<int*>(S.ctl + 7));
     MN_HIP(hipGetLastError());
+    MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 128, hipMemcpyDeviceToHost, st));
+    MN_HIP(hipStreamSynchronize(st));
+    if (w.h_ctl[7] != 0) { w.arena_per_pixel *= 2; continue; }
     // every lane-0 loop ends: the reference pops each queue entry once, and a record is pushed at most once per
     // re-score; 64 pops per initial record is far beyond what it does (4-5)
     const long long max_pops = 64LL * S.NL + 65536;

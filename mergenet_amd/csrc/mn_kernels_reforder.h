@@ -28,6 +28,37 @@ __global__ __launch_bounds__(256) void mn_ro_prepare_records(ImgParams P, XState
   S.prio[r] = mn_ro_score(S, (int)r, &mc);
 }
 
+// The maps of the constructor's loop (segment.cc:209-231), one lane per OBJECT: a map depends only on the order
+// of ITS OWN inserts, which is the creation order of the records that touch the pixel -- as source pixel
+// (slot pixel * O + k, node 2r) and as target of the pixel at -offset_k (node 2r + 1).  Bucket arrays come from
+// the shared arena by an atomic bump (where they land does not matter).  The pushes stay sequential (mn_ro_loop).
+__global__ __launch_bounds__(64) void mn_ro_build_maps(ImgParams P, RoState S, int* __restrict__ failed) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= P.N) return;
+  const int row = x / P.W, col = x - row * P.W;
+  long long ids[2 * MN_MAX_OFFSETS];                     // node ids (2r + side) in creation order of the records
+  int n = 0;
+  for (int k = 0; k < P.O; k++) {
+    // as target: the record of source pixel (row - di, col - dj) and offset k
+    const int sr = row - P.di[k], sc = col - P.dj[k];
+    if (sr >= 0 && sr < P.H && sc >= 0 && sc < P.W) ids[n++] = 2 * ((long long)(sr * P.W + sc) * P.O + k) + 1;
+    // as source
+    const int tr = row + P.di[k], tc = col + P.dj[k];
+    if (tr >= 0 && tr < P.H && tc >= 0 && tc < P.W) ids[n++] = 2 * ((long long)x * P.O + k);
+  }
+  for (int i = 1; i < n; i++) {                          // ascending record id
+    const long long v = ids[i];
+    int j = i - 1;
+    while (j >= 0 && ids[j] > v) { ids[j + 1] = ids[j]; j--; }
+    ids[j + 1] = v;
+  }
+  for (int i = 0; i < n; i++) {
+    const long long r = ids[i] >> 1;
+    if (S.r1[r] < 0) continue;
+    if (!mn_ro_insert(S, x, (int)ids[i], mn_ro_key(S.r1[r], S.r2[r]))) { atomicAdd(failed, 1); return; }
+  }
+}
+
 // ---- the queue, worked by the whole wave -------------------------------------------------------------------
 // The maps are a chain of dependent accesses and stay with lane 0; the binary heap is not: the ancestors of a
 // slot are known in advance (one round trip fetches all of them), and going down, the 62 descendants of the
@@ -122,25 +153,29 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
 #endif
   long long t_init = 0, t_pop = 0, t_merge = 0, t_mark = 0;    // (-DMN_RO_STAMPS: 100 MHz ticks per phase, MN_TRACE_EXACT prints them)
   (void)t_mark;
-  // ---- the constructor's loop (segment.cc:209-231) ----
+  // ---- the constructor's loop (segment.cc:209-231): the maps are built (mn_ro_build_maps); the pushes, in
+  //      creation order, 64 records per look ----
   long long r = S.ctl[5];
   if (r < S.NL) {
     long long left = budget * 4;
-    for (; r < S.NL && status == MN_RO_RUNNING; r++) {
-      if (left-- <= 0) { status = MN_RO_BUDGET; break; }
-      if (S.r1[r] < 0) continue;                          // (uniform)
-      int rc = MN_RO_RUNNING;
-      if (lane == 0) rc = mn_ro_init_record(S, O, r);
-      rc = __shfl(rc, 0);
-      if (rc != MN_RO_RUNNING) { status = rc; break; }
-      const float pr = S.prio[r];
-      if (pr >= 0.0f) {
+    while (r < S.NL && status == MN_RO_RUNNING) {
+      if (left <= 0) { status = MN_RO_BUDGET; break; }
+      left -= 64;
+      const long long mine = r + lane;
+      const float pr = mine < S.NL ? S.prio[mine] : -1.0f;
+      unsigned long long want = __ballot(mine < S.NL && S.r1[mine < S.NL ? mine : 0] >= 0 && pr >= 0.0f);
+      while (want) {
+        const int l = __ffsll((long long)want) - 1;
+        want &= want - 1ull;
         if (n >= S.hcap) { status = MN_RO_HEAP_FULL; break; }
-        mn_ro_wave_pushup(S, n, pr, (int)r, lane);
+        mn_ro_wave_pushup(S, n, __shfl(pr, l), (int)(r + l), lane);
         n++;
         biggest = n > biggest ? n : biggest;
       }
+      if (status != MN_RO_RUNNING) break;                 // (the cursor stays: the run is repeated from scratch anyway)
+      r += 64;
     }
+    if (r > S.NL) r = S.NL;
     if (lane == 0) S.ctl[5] = r;
     MN_RO_STAMP(t_init)
   }
