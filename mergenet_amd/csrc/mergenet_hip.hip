@@ -1787,9 +1787,21 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     hipLaunchKernelGGL(mn_rank_assign, dim3(nblk), dim3(256), 0, st, N, S, pruned,
                        (const int*)c->block_count, c->label, d_object_class);
   }
-  hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
-                     (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
-                     c->root, d_mask, d_partition, d_object_class);
+  {
+    // (the per-pixel roots are only read by the per-pixel certificate below)
+    const bool need_root = want_cert && !fused_tail && !(mode == MN_MODE_COMPONENTS && rounds == 0 && R <= MN_FIN2_MAXR);
+    int* root_out = need_root ? c->root : nullptr;
+    const bool aligned = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_object_class) |
+                                           reinterpret_cast<uintptr_t>(d_partition)) & 15) == 0;
+    if (aligned)
+      hipLaunchKernelGGL(mn_write_mask4, dim3(grid_for((size_t)N / 4, 256)), dim3(256), 0, st, N,
+                         (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
+                         root_out, d_mask, d_partition, d_object_class);
+    else
+      hipLaunchKernelGGL(mn_write_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, N,
+                         (const int*)c->parent, (const int*)c->label, (const int*)(c->scalars + 1),
+                         root_out, d_mask, d_partition, d_object_class);
+  }
   // certificate + log-likelihood (skipped on request: compute_logprob = 0, the drop-in entry's
   // setting -- the reference's c_run_segmentation returns neither)
   if (!want_cert || fused_tail) {

@@ -135,10 +135,40 @@ __global__ __launch_bounds__(256) void mn_write_mask(int N, const int* __restric
   if (p >= N) return;
   int r = p;
   while (parent[r] != r) r = parent[r];
-  root[p] = r;
+  if (root) root[p] = r;
   mask[p] = label[r];
   if (partition) partition[p] = r;
   if (p >= *num_instances) object_class[p] = -1;
+}
+
+// The same, four pixels per lane (N % 4 == 0, buffers 16-byte aligned): 16-byte loads and stores for what is
+// streamed, four gathers for the labels.  `root` may be null (only the per-pixel certificate reads it).
+__global__ __launch_bounds__(256) void mn_write_mask4(int N, const int* __restrict__ parent,
+                                                      const int* __restrict__ label,
+                                                      const int* __restrict__ num_instances,
+                                                      int* __restrict__ root, int* __restrict__ mask,
+                                                      int* __restrict__ partition,
+                                                      int* __restrict__ object_class) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * g >= N) return;
+  int4 r = *reinterpret_cast<const int4*>(parent + 4 * (size_t)g);
+  const int p0 = 4 * g;
+  // (parent is flat on the fast path; anywhere else a few steps)
+  while (parent[r.x] != r.x) r.x = parent[r.x];
+  while (parent[r.y] != r.y) r.y = parent[r.y];
+  while (parent[r.z] != r.z) r.z = parent[r.z];
+  while (parent[r.w] != r.w) r.w = parent[r.w];
+  if (root) *reinterpret_cast<int4*>(root + p0) = r;
+  *reinterpret_cast<int4*>(mask + p0) = make_int4(label[r.x], label[r.y], label[r.z], label[r.w]);
+  if (partition) *reinterpret_cast<int4*>(partition + p0) = r;
+  const int k = *num_instances;
+  if (p0 >= k) *reinterpret_cast<int4*>(object_class + p0) = make_int4(-1, -1, -1, -1);
+  else if (p0 + 3 >= k) {
+    if (p0 >= k) object_class[p0] = -1;
+    if (p0 + 1 >= k) object_class[p0 + 1] = -1;
+    if (p0 + 2 >= k) object_class[p0 + 2] = -1;
+    if (p0 + 3 >= k) object_class[p0 + 3] = -1;
+  }
 }
 
 // ---- certificate + log-likelihood over the pixel graph ----------------------------------------
