@@ -65,39 +65,28 @@ __global__ __launch_bounds__(64) void mn_ro_build_maps(ImgParams P, RoState S, i
 // hole over five levels are fetched together and the path through them is settled by cross-lane reads.  The
 // MOVES are those of std::push_heap / std::pop_heap (mn_ro_push / mn_ro_pop are the scalar text the host
 // checks against the library; the GPU tests check this form against the same vectors).
-// The first MN_RO_LT entries of the heap (its top twelve levels) live in LDS while the kernel runs: every pop
-// starts at the root and its first two rounds of five levels never leave the compute unit.
-#define MN_RO_LT 4095
-__device__ __forceinline__ unsigned long long mn_ro_hget(const RoState& S, const unsigned long long* s_top, long long i) {
-  return i < MN_RO_LT ? s_top[i] : S.heap[i];
-}
-__device__ __forceinline__ void mn_ro_hset(const RoState& S, unsigned long long* s_top, long long i, unsigned long long e) {
-  if (i < MN_RO_LT) s_top[i] = e; else S.heap[i] = e;
-}
-
-__device__ __forceinline__ void mn_ro_wave_pushup(const RoState& S, unsigned long long* s_top, long long hole, float pr,
-                                                  int rec, int lane) {
+__device__ __forceinline__ void mn_ro_wave_pushup(const RoState& S, long long hole, float pr, int rec, int lane) {
   // lane l: the ancestor at distance l + 1 of the hole (1-based index (hole + 1) >> (l + 1))
   const long long j = lane < 48 ? ((hole + 1) >> (lane + 1)) : 0;
   const bool valid = j >= 1;
   unsigned long long ae = 0ull;
-  if (valid) ae = mn_ro_hget(S, s_top, j - 1);
+  if (valid) ae = S.heap[j - 1];
   const unsigned long long movers = __ballot(valid && mn_ro_entry_prio(ae) < pr);      // __push_heap: while (parent < value)
   const int k = (~movers == 0ull) ? 64 : (__ffsll((long long)~movers) - 1);   // the first ancestor that stays
   if (lane < k) {
     const long long dest = ((hole + 1) >> lane) - 1;
-    mn_ro_hset(S, s_top, dest, ae);
+    S.heap[dest] = ae;
   }
   if (lane == 0) {
     const long long dest = ((hole + 1) >> k) - 1;
-    mn_ro_hset(S, s_top, dest, mn_ro_entry(pr, rec));
+    S.heap[dest] = mn_ro_entry(pr, rec);
   }
 }
 
 // pop: returns the top entry and, fetched while the hole travels down, the popped record's stored priority and
 // second end (what the caller's stale test reads)
-__device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, unsigned long long* s_top, long long& n, float* pr_out,
-                                               int* rec_out, float* rec_prio, int* rec_r2, int lane) {
+__device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, float* pr_out, int* rec_out,
+                                               float* rec_prio, int* rec_r2, int lane) {
   // ONE round trip: the top (lane 62), the last entry (lane 63) and the 62 descendants of the root over five levels
   const long long len = n - 1;
   const int d = 31 - __clz(lane + 2);                    // lane l < 62: level d = floor(log2(l + 2)) (1..5) ...
@@ -105,7 +94,7 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, unsigned long l
   float p = 0.0f; int rr = 0;
   {
     const long long idx0 = lane < 62 ? (long long)lane + 1 : (lane == 62 ? 0 : len);
-    if (idx0 < n) { const unsigned long long e = mn_ro_hget(S, s_top, idx0); p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
+    if (idx0 < n) { const unsigned long long e = S.heap[idx0]; p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
   }
   *pr_out = __shfl(p, 62); *rec_out = __shfl(rr, 62);
   const float vp = __shfl(p, 63);
@@ -122,7 +111,7 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, unsigned long l
       const long long idx = (((hole + 1) << d) + jl) - 1;
       const bool valid = lane < 62 && idx < len;
       p = 0.0f; rr = 0;
-      if (valid) { const unsigned long long e = mn_ro_hget(S, s_top, idx); p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
+      if (valid) { const unsigned long long e = S.heap[idx]; p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
     }
     fetched = false;
     long long cur = hole;
@@ -133,7 +122,7 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, unsigned long l
         const int lr = (1 << lev) - 2 + 2 * curj + 1, ll = lr - 1;
         const float pR = __shfl(p, lr), pL = __shfl(p, ll);
         const int chosen = (pR < pL) ? ll : lr;          // the right child among equals
-        if (lane == chosen) mn_ro_hset(S, s_top, cur, mn_ro_entry(p, rr));
+        if (lane == chosen) S.heap[cur] = mn_ro_entry(p, rr);
         curj = chosen - ((1 << lev) - 2);
         cur = (((hole + 1) << lev) + curj) - 1;
       }
@@ -142,24 +131,21 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, unsigned long l
   }
   if ((len & 1) == 0 && hole == (len - 2) / 2) {         // a last node with a left child only
     const long long child = 2 * hole + 1;
-    if (lane == 0) mn_ro_hset(S, s_top, hole, mn_ro_hget(S, s_top, child));
+    if (lane == 0) S.heap[hole] = S.heap[child];
     hole = child;
   }
-  mn_ro_wave_pushup(S, s_top, hole, vp, vr, lane);       // ... and back up with the last entry's value
+  mn_ro_wave_pushup(S, hole, vp, vr, lane);              // ... and back up with the last entry's value
 }
 
 // ONE wave: lane 0 runs the maps and the records (mn_reforder.h), the wave the queue.  Comes back when `budget`
 // pops (4 x budget records of the constructor's loop) are used up: the state is in memory, the next launch goes on.
 __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long budget) {
   __shared__ int s_nodes[66];                            // the records of a walk (64), their count, the next node
-  __shared__ unsigned long long s_top[MN_RO_LT];         // the top of the heap
   const int lane = threadIdx.x;
   const long long st0 = S.ctl[0];
   if (st0 != MN_RO_RUNNING && st0 != MN_RO_BUDGET) return;
   long long n = S.ctl[1], biggest = S.ctl[6], pops = 0;
   int status = MN_RO_RUNNING;
-  for (long long i = lane; i < n && i < MN_RO_LT; i += 64) s_top[i] = S.heap[i];
-  __syncthreads();
 #ifdef MN_RO_STAMPS
 #define MN_RO_STAMP(acc) { const long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; }
 #else
@@ -182,7 +168,7 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
         const int l = __ffsll((long long)want) - 1;
         want &= want - 1ull;
         if (n >= S.hcap) { status = MN_RO_HEAP_FULL; break; }
-        mn_ro_wave_pushup(S, s_top, n, __shfl(pr, l), (int)(r + l), lane);
+        mn_ro_wave_pushup(S, n, __shfl(pr, l), (int)(r + l), lane);
         n++;
         biggest = n > biggest ? n : biggest;
       }
@@ -199,7 +185,7 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
     while (n > 0) {
       if (pops >= budget) { status = MN_RO_BUDGET; break; }
       float q, stored; int rec, second;
-      mn_ro_wave_pop(S, s_top, n, &q, &rec, &stored, &second, lane);
+      mn_ro_wave_pop(S, n, &q, &rec, &stored, &second, lane);
       pops++;
       MN_RO_STAMP(t_pop)
       if (q != stored) continue;                          // a stale entry (segment.cc:554)
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
             const float pr_val = __shfl(pp, i);
             if (pr_rec >= 0) {
               if (n >= S.hcap) { rc = MN_RO_HEAP_FULL; break; }
-              mn_ro_wave_pushup(S, s_top, n, pr_val, pr_rec, lane);
+              mn_ro_wave_pushup(S, n, pr_val, pr_rec, lane);
               n++;
               biggest = n > biggest ? n : biggest;
             }
@@ -259,14 +245,12 @@ __global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long bud
         MN_RO_STAMP(t_merge)
       } else if (f >= 0.0f) {
         if (n >= S.hcap) { status = MN_RO_HEAP_FULL; break; }
-        mn_ro_wave_pushup(S, s_top, n, f, rec, lane);
+        mn_ro_wave_pushup(S, n, f, rec, lane);
         n++;
         biggest = n > biggest ? n : biggest;
       }
     }
   }
-  __syncthreads();
-  for (long long i = lane; i < n && i < MN_RO_LT; i += 64) S.heap[i] = s_top[i];       // (the next launch reads it back)
   if (lane == 0) {
     S.ctl[0] = status; S.ctl[1] = n; S.ctl[3] += pops; S.ctl[6] = biggest;
     S.ctl[8] += t_init; S.ctl[9] += t_pop; S.ctl[10] += t_merge;
