@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     // (parent -> root -> ...), not a stream, and these used to queue up behind the chase
     constexpr int G = MN_CC_SUMS_G;
     int4 r = *reinterpret_cast<const int4*>(S.parent + 4 * (size_t)i);
+    const int4 r_in = r;
     const uchar4 b = *reinterpret_cast<const uchar4*>(cls0 + 4 * (size_t)i);
     int g[G];
 #pragma unroll
@@ -1269,7 +1270,9 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
     r.y = r.y == r.x ? r.x : mn_cc_root_ro(S.parent, r.y);
     r.z = r.z == r.x ? r.x : mn_cc_root_ro(S.parent, r.z);
     r.w = r.w == r.x ? r.x : mn_cc_root_ro(S.parent, r.w);
-    *reinterpret_cast<int4*>(S.parent + 4 * (size_t)i) = r;
+    // (after the flatten stage only the pixels the hook stage re-rooted are not flat: 8 MB fewer written)
+    if (r.x != r_in.x || r.y != r_in.y || r.z != r_in.z || r.w != r_in.w)
+      *reinterpret_cast<int4*>(S.parent + 4 * (size_t)i) = r;
     const bool same = r.x == r.y && r.x == r.z && r.x == r.w;
     const int s0 = mn_lds_root_slot(s_root, r.x);
     // a wave inside one component -- most are -- would put 64 atomics on ONE LDS address per class,
