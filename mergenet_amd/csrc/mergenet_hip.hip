@@ -2058,8 +2058,15 @@ extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float*
   free(Ps);
   if (rc != MN_OK) { g_last_status = rc; return rc; }
   // hand-over and output stage of every image (labels, mask, class table, certificate, log-likelihood)
+  long long tie_limit = MN_TIE_LIMIT_RECORDS;
+  if (const char* e = getenv("MN_TIE_LIMIT")) tie_limit = atoll(e);
   for (int i = 0; i < count; i++) {
-    ctxs[i]->xw.prerun = 1;
+    // (an image the tie policy sends to the reference-order loop takes the single-image path from the start)
+    const bool ref_possible = o.variant == MN_VARIANT_CSEGMENT;
+    const bool redo = ref_possible && (o.tie_order == MN_TIES_REFERENCE ||
+                                       (o.tie_order == MN_TIES_DEFAULT && ctxs[i]->xw.h_ctl->tied_steps > 0 &&
+                                        (long long)W * H * offset_dim <= tie_limit));
+    ctxs[i]->xw.prerun = redo ? 0 : 1;
     const int r = segment_attempt(ctxs[i], d_class_pred[i], class_dim, d_adj_pred[i], offset_dim, W, H, num_classes,
                                   offset_list, d_mask[i], d_object_class[i], d_partition ? d_partition[i] : nullptr,
                                   &o, stream, stats ? &stats[i] : nullptr, MN_MODE_EXACT, false);

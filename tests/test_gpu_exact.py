@@ -322,3 +322,26 @@ def test_tied_pops_are_counted():
     assert syn["tie_order_used"] == seg.MN_TIES_LOWEST_ID
     fast = _run(gu.load("cseg_synth_64x128_n15"), seg.MN_MODE_COMPONENTS, require_proof=-1)[3]
     assert fast["tied_steps"] == 0 and fast["tied_merges"] == 0
+
+
+def test_a_batch_honours_the_tie_policy(oracle):
+    """mn_segment_exact_batch: an image whose exact run met tied pops and is small enough is redone in the
+    reference's order, as a single call would do -- the tie-decided vectors come out as the reference's."""
+    import torch
+    gs = [gu.load(n) for n in TIE_DECIDED]
+    g0 = gs[0]
+    H, W, C = g0["spec"]["H"], g0["spec"]["W"], g0["spec"]["C"]
+    sdb, omf, bias = g0["spec"]["opts"]
+    o = seg.default_options(same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias,
+                            mode=seg.MN_MODE_EXACT, clip_inputs=1)
+    cps = [torch.from_numpy(np.ascontiguousarray(g["class_probs"], dtype=np.float32)).cuda() for g in gs]
+    sps = [torch.from_numpy(np.ascontiguousarray(g["sameness_probs"], dtype=np.float32)).cuda() for g in gs]
+    batch = seg.ExactBatch(H, W, C, len(g0["offsets"]), len(gs))
+    try:
+        res = batch.segment(cps, sps, g0["offsets"], o)
+        for g, (mask, table, part, st) in zip(gs, res):
+            assert st["tie_order_used"] == seg.MN_TIES_REFERENCE and st["tied_steps"] > 0
+            assert oracle.masks_equivalent(mask.cpu().numpy(), seg._class_list(table.cpu().numpy()),
+                                           g["mask"], g["object_class"]), st
+    finally:
+        batch.close()
