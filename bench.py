@@ -99,7 +99,11 @@ def exact_engine_sample(seg, synth, offs, device):
     from mergenet_amd import labels as ck
     out = []
     for (name, hh, ww, maker) in (("cseg_synth_512x1024_s1000", 512, 1024, lambda: synth.synth_v1(512, 1024, C, offs, 1000)),
-                                  ("cseg_blur_256x512_r2", 256, 512, None)):
+                                  ("cseg_blur_256x512_r2", 256, 512, None),
+                                  # an image whose instance borders the ORDER AMONG BIT-EQUAL PRIORITIES decides: the
+                                  # exact engine meets tied pops and the image is redone in the reference's own
+                                  # order (its std::priority_queue and unordered_map restated: mn_reforder.h)
+                                  ("cseg_blur4_128x256_s5100", 128, 256, None)):
         golden = os.path.join(ROOT, "tests", "golden", name + ".npz")
         if not os.path.exists(golden):
             continue
@@ -124,6 +128,7 @@ def exact_engine_sample(seg, synth, offs, device):
         same = bool(ck.masks_equivalent(mask.cpu().numpy(), got, z["mask"], [int(c) for c in z["object_class"]]))
         out.append({"image": name, "seconds": round(dt, 3), "value": round(hh * ww / dt / 1e6, 4), "unit": "Mpixel/s",
                     "steps": st["finisher_steps"], "merges": st["merges"], "proof": st["proof"],
+                    "tied_steps": st["tied_steps"], "tie_order_used": st["tie_order_used"],
                     "equals_reference": same})
         m.close()
     # the loop is one wavefront per image: a batch of images in ONE launch, a workgroup each
