@@ -135,7 +135,7 @@ def exact_engine_sample(seg, synth, offs, device):
     # (mn_segment_exact_batch), multiplies the rate -- the reference scales the same way, by processes (--num-jobs)
     pool_out = None
     try:
-        count = 128
+        count = 192
         names = ["cseg_synth_512x1024_s1000", "cseg_synth_512x1024_s1001", "cseg_synth_512x1024_s1002"]
         imgs = []
         for nm in names:

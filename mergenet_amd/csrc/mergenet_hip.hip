@@ -232,8 +232,8 @@ static hipError_t x_alloc(mn_context* c, T** p, size_t n) {
 
 // Sizes the workspace for an image of N pixels, O offsets, C classes.  Per pixel (C = 9, O = 10):
 // records 20 B x O, pair table 32-64 B x O (load <= 0.5 at the start, falling: pairs only disappear), class
-// vectors 4 B x C, objects 20 B, adjacency arena 4 B x (64 + 192) (152 words per pixel are used at 512x1024;
-// a run that fills the arena or the table is repeated with twice as much: exact_run): ~1.7 KB, 3.6 GB for
+// vectors 4 B x C, objects 20 B, adjacency arena 4 B x (64 + 11 O + 8) (150 words per pixel are used at O = 10, 230 at O = 16;
+// a run that fills the arena or the table is repeated with twice as much: exact_run): ~1.7 KB, 3.5 GB for
 // 1024 x 2048 (of 288 GB) -- the workspace bounds the images in flight (mn_segment_exact_batch).
 static int x_ensure(mn_context* c, int N, int O, int C) {
   mn_context::XWork& w = c->xw;
@@ -244,7 +244,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   const size_t NB = (NL + B - 1) / B;
   const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
   if (w.arena_extra <= 0) {
-    w.arena_extra = 192;
+    w.arena_extra = 11 * O + 8;                       // (measured use: 8.6-8.9 entries per pixel and offset at O = 10, 10.3-10.6 at O = 16)
     if (const char* e = getenv("MN_X_ARENA_EXTRA")) { const int v = atoi(e); if (v > 0) w.arena_extra = v; }   // (tests)
     w.table_shift = 1;
   }
