@@ -68,6 +68,20 @@ enum mn_mode {
 };
 
 enum mn_tie_order { MN_TIES_DEFAULT = 0, MN_TIES_REFERENCE = 1, MN_TIES_LOWEST_ID = 2 };
+/* mn_stats.proof */
+enum mn_proof {
+  MN_PROOF_NONE = 0,             /* measured only: an approximation of the sequential order on order-dependent inputs */
+  MN_PROOF_CERTIFICATE = 1,      /* ANY order of the lazy greedy ends in this partition          */
+  MN_PROOF_SEQUENTIAL = 2,       /* the reference's sequential order was run and no choice among bit-equal priorities
+                                    was left to the engine: every pop was forced (tied_steps == 0) or the reference's
+                                    own heap / hash-map order among equals was reproduced (tie_order_used ==
+                                    MN_TIES_REFERENCE)                                                               */
+  MN_PROOF_SEQUENTIAL_TIES = 3   /* the sequential order was run, but some pops chose among bit-equal priorities by
+                                    the engine's rule (lowest record id) where the reference's std::priority_queue
+                                    chooses by heap position: equal to the reference on every vector held at these
+                                    sizes, differing on the radius-4 blurred vectors; require_proof = 1 redoes such an
+                                    image in the reference's order                                                   */
+};
 #define MN_TIE_LIMIT_RECORDS 400000   /* MN_TIES_DEFAULT: largest image (initial records) redone in the reference's order */
 
 typedef struct mn_options {
@@ -114,7 +128,10 @@ typedef struct mn_options {
                                   instead of the exact engine -- kept for comparison                */
   int require_proof;           /* what happens to a result that is not PROVEN equal to the reference's
                                   sequential order (stats.proof == 0): 1 = it is redone in MN_MODE_EXACT,
-                                  whatever mode was asked for; -1 = it is handed back as it is (the
+                                  whatever mode was asked for, and -- if that run chose among bit-equal
+                                  priorities by its own rule (proof 3) -- once more in the reference's order
+                                  among equals (tie_order MN_TIES_REFERENCE; MN_ERR_UNPROVEN for the Python
+                                  variant, whose heapq order is not restated); -1 = it is handed back as it is (the
                                   speculative fast path: an approximation on order-dependent inputs,
                                   stats.proof tells); 0 (default) = by mode: AUTO redoes it, an explicit
                                   MN_MODE_ROUNDS / MN_MODE_COMPONENTS request is taken as a request for
@@ -133,10 +150,11 @@ typedef struct mn_options {
                                   by ONE lane, the heap by its wave: the reference's very partition also on
                                   maps with plateaus of equal values, at 20-40x the exact engine's time
                                   (csegment variant only).  MN_TIES_DEFAULT (0): the exact engine first; if it
-                                  met tied pops (stats.tied_steps > 0: only then can the two rules differ) and
-                                  the image has at most MN_TIE_LIMIT_RECORDS initial records, it is redone in
-                                  the reference's order; larger images keep the exact engine's answer and
-                                  say so (stats.tie_order_used, stats.tied_steps)                          */
+                                  met tied pops whose choices conflict (stats.tied_conflicts > 0: only then can
+                                  the two rules end in different states) and the image has at most
+                                  MN_TIE_LIMIT_RECORDS initial records, it is redone in the reference's order;
+                                  larger images keep the exact engine's answer and say so (stats.proof == 3,
+                                  stats.tie_order_used, stats.tied_steps, stats.tied_conflicts)              */
 } mn_options;
 
 typedef struct mn_stats {
@@ -165,12 +183,7 @@ typedef struct mn_stats {
   float ms_cc_sums;            /* mn_cc_class_sums: reads the C class planes                            */
   float ms_cc_edges;           /* mn_cc_sign: THE read of the O sameness planes (masks, negative edges)  */
   float ms_cc_cross;           /* mn_cc_cross: negative-edge list -> records between components         */
-  int proof;                   /* why the partition equals the reference's: 0 = not proven (measured
-                                  only; an approximation of the sequential order on order-dependent
-                                  inputs), 1 = certificate (ANY order of the lazy greedy ends here,
-                                  DESIGN.md section 5), 2 = the sequential order itself was run
-                                  (MN_MODE_EXACT; among bit-equal priorities see tie_order / tie_order_used /
-                                  tied_steps)                                                         */
+  int proof;                   /* enum mn_proof: why (and whether) the partition equals the reference's     */
   int cores_condemned;         /* general rounds: 1 if a core held an edge that was not positive and
                                   fell apart again (mn_core_check); 0 otherwise                    */
   int tied_steps;              /* MN_MODE_EXACT: pops at which a second live record held the bit-equal stored
@@ -181,7 +194,10 @@ typedef struct mn_stats {
                                   they do not (radius-4 blurred, clipped maps)                             */
   int tied_merges;             /* ... of which were merges */
   int tie_order_used;          /* MN_MODE_EXACT: MN_TIES_LOWEST_ID or MN_TIES_REFERENCE (0 on the other paths) */
-  int reserved_i;
+  int tied_conflicts;          /* MN_MODE_EXACT: 0 = no tied pop's choice touched what another tied choice touched:
+                                  the tied merges commute and every order among equals ends in this state (then
+                                  proof == 2 even with tied_steps > 0); > 0 = at least one did (the engine stops
+                                  looking at the first: a yes / no, not a count).  mn_kernels_exact.h "ties"      */
 } mn_stats;
 
 typedef struct mn_context mn_context;

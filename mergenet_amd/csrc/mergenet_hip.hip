@@ -202,7 +202,7 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
 // ---- exact engine: workspace ------------------------------------------------------------------------
 static void x_free(mn_context* c) {
   XState& X = c->xw.X;
-  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl, X.mlog};
+  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl, X.mlog, X.ostamp, X.tstack};
   for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
     if (dev[i]) (void)hipFree(dev[i]);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
@@ -269,6 +269,8 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
     MN_HIP(x_alloc(c, &X.overflow, ovf_cap));
     MN_HIP(x_alloc(c, &X.l1g, (size_t)MN_X_MAXBLOCKS));
     MN_HIP(x_alloc(c, &X.ctl, 1));
+    MN_HIP(x_alloc(c, &X.ostamp, (size_t)N));
+    MN_HIP(x_alloc(c, &X.tstack, (size_t)MN_X_TSTACK));
     MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), sizeof(XCtl)));
     w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = nbuckets; w.arena_cap = arena_cap;
     w.leaf_cap = leaf_cap;
@@ -285,6 +287,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   X.NL = (unsigned)NL;
   X.cap0 = cap0;
   X.parent = c->parent;
+  X.dbg = getenv("MN_X_FORCE_RELOCATE") ? 1 : 0;                       // (tests)
   // diagnostic: MN_X_MERGELOG=<file> keeps the sequence of merges (survivor, absorbed, record, priority)
   if (getenv("MN_X_MERGELOG") && !X.mlog) {
     if (hipMalloc(reinterpret_cast<void**>(&X.mlog), (size_t)N * 16) == hipSuccess) X.mlog_cap = N;
@@ -1044,7 +1047,9 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   MN_HIP(hipMemsetAsync(X.hs, 0xFF, ((size_t)X.bmask + 1) * 4 * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.arena, 0xFF, N * (size_t)X.cap0 * sizeof(unsigned), st));
   MN_HIP(hipMemsetAsync(X.leaf, 0, (((size_t)X.NB << X.Blog) + 1024) * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.ostamp, 0, N * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
+  w.h_ctl->ttrack = getenv("MN_X_NO_TIE_TRACKING") ? 0 : 1;          // (timing comparisons)
   w.h_ctl->bump = (unsigned long long)N * (unsigned long long)X.cap0;
   MN_HIP(hipMemcpyAsync(X.ctl, w.h_ctl, sizeof(XCtl), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(mn_x_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->cls0);
@@ -1077,7 +1082,7 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
     for (int i = 0; i < n; i++) {
       const XState& X = cs[i]->xw.X;
       hx[i] = X;
-      const size_t l = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + 64;
+      const size_t l = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + (size_t)MN_X_TSTACK * 8 + 64;
       if (l > lds) lds = l;
       // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per
       // record (plus slack) is the hard stop of a run, whatever the input
@@ -1092,7 +1097,7 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
   }
   if (!w0.lds_ready) {
     MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_x_run),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     w0.lds_ready = 1;
   }
   long long per_launch = 1LL << 24;                  // steps per launch (MN_X_BUDGET: tests of the relaunch)
@@ -1178,6 +1183,16 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
   mn_context::XWork& w = c->xw;
   XState& X = w.X;
   const size_t N = (size_t)P.N;
+  if (getenv("MN_X_CHECK_SLOTS") && c->tie_used != MN_TIES_REFERENCE) {
+    // tests: records and pair-table slots must point at each other at the end of a run
+    const size_t n = (size_t)X.NL > ((size_t)X.bmask + 1) * 4 ? (size_t)X.NL : ((size_t)X.bmask + 1) * 4;
+    hipLaunchKernelGGL(mn_x_check_slots, dim3(grid_for(n, 256)), dim3(256), 0, st, X);
+    long long errs = -1;
+    MN_HIP(hipMemcpyAsync(&errs, &X.ctl->slot_errors, sizeof(errs), hipMemcpyDeviceToHost, st));
+    MN_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "exact engine: pair-table check: %lld errors (slow inserts %lld)\n", errs, w.h_ctl->slow_inserts);
+    if (errs != 0) return MN_ERR_INTERNAL;
+  }
   if (getenv("MN_TRACE_EXACT"))
     fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld slow inserts %lld set-up overflow %d arena %llu of %llu\n",
             w.h_ctl->steps, w.h_ctl->merges, w.h_ctl->rescans, w.h_ctl->reallocs, w.h_ctl->folded,
@@ -1323,6 +1338,13 @@ static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
   return MN_ERR_CAPACITY;
 }
 
+// Did the run leave anything to the engine's own rule among bit-equal priorities?  Tied pops whose choices touched
+// disjoint parts of the image commute (mn_kernels_exact.h, "ties"): only a tie CONFLICT can make the reference's
+// heap order end elsewhere.
+static bool x_ties_unresolved(const XCtl* h) {
+  return h->tied_steps > 0 && (h->ttrack == 0 || h->tied_conflicts > 0);
+}
+
 // set-up, loop and hand-over of ONE image; in a batch (mn_segment_exact_batch) set-up and loop have run for
 // all images together and only the hand-over is left (xw.prerun)
 static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
@@ -1344,13 +1366,15 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
     // small image that had some is redone the reference's way
     long long limit = MN_TIE_LIMIT_RECORDS;
     if (const char* e = getenv("MN_TIE_LIMIT")) limit = atoll(e);
-    if (c->tie_ref == MN_TIES_DEFAULT && ref_possible && c->xw.h_ctl->tied_steps > 0 &&
+    if (c->tie_ref == MN_TIES_DEFAULT && ref_possible && x_ties_unresolved(c->xw.h_ctl) &&
         (long long)P.N * P.O <= limit) {
-      const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
+      const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges, tc = c->xw.h_ctl->tied_conflicts;
+      const int tt = c->xw.h_ctl->ttrack;
       rc = run_reforder(c, P, st);
       if (rc != MN_OK) return rc;
       c->tie_used = MN_TIES_REFERENCE;
       c->xw.h_ctl->tied_steps = ts; c->xw.h_ctl->tied_merges = tm;     // (what the exact engine met)
+      c->xw.h_ctl->tied_conflicts = tc; c->xw.h_ctl->ttrack = tt;
     }
   } else {
     MN_HIP(hipEventRecord(c->ev[1], st));
@@ -1392,19 +1416,30 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->cert_class_violations = c->h_scalars[3];
     stats->cert_record_violations = c->h_scalars[4];
     stats->certified = (want_cert && c->h_scalars[0] == 0 && c->h_scalars[3] == 0 && c->h_scalars[4] == 0 && cert_opts) ? 1 : 0;
-    stats->proof = stats->certified ? 1 : (mode == MN_MODE_EXACT ? 2 : 0);
+    // 2 only where the pop order was forced or the reference's own order among equals was run; an exact-engine
+    // result that met tied pops under its own lowest-id rule says 3 (advisor r3 / verdict r3: a held vector
+    // shows the two rules can part)
+    stats->proof = MN_PROOF_NONE;
+    if (stats->certified) stats->proof = MN_PROOF_CERTIFICATE;
+    else if (mode == MN_MODE_EXACT && c->xw.h_ctl)
+      stats->proof = (c->tie_used == MN_TIES_REFERENCE || c->xw.h_ctl->tied_steps == 0 ||
+                      (c->xw.h_ctl->ttrack != 0 && c->xw.h_ctl->tied_conflicts == 0)) ? MN_PROOF_SEQUENTIAL
+                                                                                       : MN_PROOF_SEQUENTIAL_TIES;
     stats->num_instances = c->h_scalars[1];
     stats->num_objects = c->h_scalars[2];
     stats->rounds = rounds;
     stats->cores_condemned = c->cores_used ? (c->h_scalars[9] != 0) : 0;
     stats->finisher_steps = c->h_cnt->finisher_steps;
-    stats->tied_steps = stats->tied_merges = 0;
+    stats->tied_steps = stats->tied_merges = stats->tied_conflicts = 0;
     stats->tie_order_used = 0;
     if (mode == MN_MODE_EXACT && c->xw.h_ctl && (!(opts->debug_flags & 256) || c->xw.prerun)) {
       stats->tie_order_used = c->tie_used;
       const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
       stats->tied_steps = (int)(ts > 0x7FFFFFFF ? 0x7FFFFFFF : ts);
       stats->tied_merges = (int)(tm > 0x7FFFFFFF ? 0x7FFFFFFF : tm);
+      // (tracking switched off by the environment: unknown, reported as a conflict wherever a pop was tied)
+      const long long tc = c->xw.h_ctl->tied_conflicts;
+      stats->tied_conflicts = (c->xw.h_ctl->ttrack == 0 && tc == 0 && ts > 0) ? 1 : (int)(tc > 0x7FFFFFFF ? 0x7FFFFFFF : tc);
     }
     stats->initial_records = R0;
     stats->merges = merges;
@@ -2002,6 +2037,20 @@ extern "C" int mn_segment_finish(mn_context* c, mn_stats* stats) {
     if (rc == MN_ERR_CAPACITY) rc = MN_ERR_UNPROVEN;      // (no room for the engine's workspace)
     if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
   }
+  // require_proof = 1 does not take "the sequential order, equal priorities in creation order" for proven: the
+  // image is redone in the reference's own order among equals (mn_reforder.h: slow, csegment variant only)
+  if (rc == MN_OK && q.opts.require_proof > 0 && q.stats.proof == MN_PROOF_SEQUENTIAL_TIES) {
+    if (q.opts.variant == MN_VARIANT_CSEGMENT) {
+      mn_options o2 = q.opts;
+      o2.tie_order = MN_TIES_REFERENCE;
+      rc = segment_attempt(c, q.d_class, q.class_dim, q.d_adj, q.offset_dim, q.W, q.H, q.num_classes,
+                           q.offs, q.d_mask, q.d_objcls, q.d_part, &o2, q.stream, &q.stats, MN_MODE_EXACT, false);
+      if (rc == MN_ERR_CAPACITY) rc = MN_ERR_UNPROVEN;
+    } else {
+      rc = MN_ERR_UNPROVEN;            // (the Python variant's heapq / dict order is not restated)
+    }
+    if (rc == MN_ERR_UNPROVEN) { q.stats.status = rc; g_last_status = rc; }
+  }
   if (stats) *stats = q.stats;
   q.active = 0;
   g_host_us[1] += t_synced - t_in; g_host_us[2] += host_now_us() - t_synced; g_host_n[1]++;
@@ -2064,7 +2113,7 @@ extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float*
     // (an image the tie policy sends to the reference-order loop takes the single-image path from the start)
     const bool ref_possible = o.variant == MN_VARIANT_CSEGMENT;
     const bool redo = ref_possible && (o.tie_order == MN_TIES_REFERENCE ||
-                                       (o.tie_order == MN_TIES_DEFAULT && ctxs[i]->xw.h_ctl->tied_steps > 0 &&
+                                       (o.tie_order == MN_TIES_DEFAULT && x_ties_unresolved(ctxs[i]->xw.h_ctl) &&
                                         (long long)W * H * offset_dim <= tie_limit));
     ctxs[i]->xw.prerun = redo ? 0 : 1;
     const int r = segment_attempt(ctxs[i], d_class_pred[i], class_dim, d_adj_pred[i], offset_dim, W, H, num_classes,

@@ -39,6 +39,7 @@
 #define MN_X_HEMPTY 0xFFFFFFFFFFFFFFFFull
 #define MN_X_DIRTY 0xFFFFFFFFFFFFFFFFull
 #define MN_X_MAXBLOCKS 16384
+#define MN_X_TSTACK 1024
 
 enum { MN_X_RUNNING = 0, MN_X_DONE = 1, MN_X_BUDGET = 2, MN_X_ARENA_FULL = 3, MN_X_HASH_FULL = 4 };
 
@@ -50,6 +51,11 @@ struct XCtl {
   long long stamps[16];       // -DMN_X_STAMPS (diagnostic build): cycles per phase of the loop
   long long tied_steps;       // pops at which a second live record held the bit-equal stored priority
   long long tied_merges;      // ... of which merged
+  long long slot_errors;      // MN_X_CHECK_SLOTS (tests): records / table slots that do not point at each other
+  // tie-conflict tracking (see "ties" below): state kept across launches of the loop
+  long long tied_conflicts;   // > 0: a choice among bit-equal priorities touched what another such choice touched
+  int tdepth, tpairs, ttied;  // nesting stack: entries, adjacent entries with equal words, entries popped while tied
+  int ttrack;                 // 1: tracking (stops at the first conflict: the verdict is a yes / no)
 };
 
 // one record (AdjacencyRecord, segment.h:175-232): ONE 16-byte load
@@ -94,6 +100,9 @@ struct XState {
   int cap0;                   // arena entries every pixel starts with
   int* mlog;                  // diagnostic (MN_X_MERGELOG): 4 ints per merge {survivor, absorbed, record, priority bits}
   long long mlog_cap;         // merges the log holds (0: none)
+  int dbg;                    // bit 0 (MN_X_FORCE_RELOCATE, tests): a slow insert moves an occupant whenever it can
+  unsigned* ostamp;           // [N] index of the last event (pop) that touched the object: tie-conflict tracking
+  u64* tstack;                // [MN_X_TSTACK] the nesting stack between launches
   XCtl* ctl;
 };
 
@@ -221,17 +230,19 @@ __device__ __forceinline__ float mn_x_score1(const ImgParams& P, const float* la
 // Insertion by ONE lane with everything read afresh (the rare paths: a record the parallel set-up could
 // not place, or a lane of a merge pass that lost its slot to another lane): a free slot of either
 // bucket, else one occupant is moved to ITS other bucket.  Returns the slot, MN_X_INVALID if no room.
-__device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned bmask, u64 key, unsigned rid, float S) {
+__device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned bmask, u64 key, unsigned rid, float S,
+                                                  bool relocate_first = false) {
   unsigned b1, b2;
   mn_x_buckets(key, bmask, &b1, &b2);
   XSlot ns; ns.key = key; ns.rid = rid; ns.S = S;
-  for (int t = 0; t < 8; t++) {
+  for (int t = 0; t < 8 && !relocate_first; t++) {
     const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
     if (hs[s].key == MN_X_HEMPTY) { hs[s] = ns; return s; }
   }
   for (int t = 0; t < 8; t++) {
     const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
     const XSlot v = hs[s];
+    if (v.key == MN_X_HEMPTY) continue;          // (relocate_first: free slots are taken by the last loop)
     unsigned v1, v2;
     mn_x_buckets(v.key, bmask, &v1, &v2);
     const unsigned alt = ((s >> 2) == v1) ? v2 : v1;
@@ -242,6 +253,10 @@ __device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned
         hs[s] = ns;
         return s;
       }
+  }
+  for (int t = 0; t < 8 && relocate_first; t++) {
+    const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
+    if (hs[s].key == MN_X_HEMPTY) { hs[s] = ns; return s; }
   }
   return MN_X_INVALID;
 }
@@ -419,6 +434,56 @@ __device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int 
   if (lane == 0) l2[g] = v;
 }
 
+
+// ---- ties: does the ORDER among bit-equal priorities matter? -------------------------------------------
+// The reference pops bit-equal priorities as its binary heap happens to hold them (segment.h:270-275 compares the
+// float only); the engine takes the lowest record id.  The two sequences can only part where a pop had an equal
+// rival.  Events (pops) nest: event j hangs under the last earlier event i with word(i) <= word(j) such that every
+// event between them is above word(i) -- the suffix minima of the popped words, kept as a stack (words
+// non-decreasing, event indices increasing).  Two SIBLINGS with equal words are what a tie rule orders; their
+// subtrees (everything popped above their word before the queue falls back to it) commute iff they touch
+// disjoint objects.  ostamp[o] = index of the last event that touched object o (endpoints of a pop, third
+// objects of a merge).  An event touching an object whose last toucher s lies in the subtree of a tied sibling of
+// one of its ancestors-or-self is a CONFLICT: with the stack, that is "the first entry with index > s and the
+// entry before it carry the same word".  Second kind: a merge re-scores or retires a record whose stored word
+// equals the word of an entry on the stack that was popped while tied -- a rival whose own turn might have come
+// first.  No conflict in a whole run => every order among equals gives the same final state (DESIGN.md
+// section 5); tests/tools/exact_model.cpp implements the same criterion on the CPU.
+// Stack entry: word << 32 | event index << 1 | popped-while-tied.
+__device__ __forceinline__ unsigned mn_x_te_word(u64 e) { return (unsigned)(e >> 32); }
+__device__ __forceinline__ unsigned mn_x_te_ev(u64 e) { return ((unsigned)e) >> 1; }
+
+// wave-uniform stamp s: conflict?
+__device__ __forceinline__ bool mn_x_tie_touch_uniform(const u64* stk, int depth, unsigned s, int lane) {
+  if (s == 0u) return false;
+  for (int base = 0; base < depth; base += 64) {
+    const int j = base + lane;
+    const u64 e = (j < depth) ? stk[j] : 0ull;
+    const u64 b = __ballot(j < depth && mn_x_te_ev(e) > s);
+    if (b) {
+      const int i = base + __ffsll((long long)b) - 1;
+      if (i == 0) return false;
+      return mn_x_te_word(stk[i]) == mn_x_te_word(stk[i - 1]);
+    }
+  }
+  return false;
+}
+// per-lane stamp s
+__device__ __forceinline__ bool mn_x_tie_touch_lane(const u64* stk, int depth, unsigned s) {
+  if (s == 0u) return false;
+  int lo = 0, hi = depth;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (mn_x_te_ev(stk[mid]) > s) hi = mid; else lo = mid + 1; }
+  if (lo >= depth || lo == 0) return false;
+  return mn_x_te_word(stk[lo]) == mn_x_te_word(stk[lo - 1]);
+}
+// per-lane: a record whose stored word w (0 = not queued) is modified: a rival of an event on the stack?
+__device__ __forceinline__ bool mn_x_tie_rival_lane(const u64* stk, int depth, unsigned w) {
+  if (w == 0u) return false;
+  int lo = 0, hi = depth;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (mn_x_te_word(stk[mid]) >= w) hi = mid; else lo = mid + 1; }
+  return lo < depth && mn_x_te_word(stk[lo]) == w;
+}
+
 // One workgroup (= one wavefront) per image: block b runs the loop of image b of a batch (images are
 // independent; the reference scales the same way, by processes).
 __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps, const XState* __restrict__ Xs,
@@ -436,6 +501,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   float* sh_lpa = reinterpret_cast<float*>(l2 + X.NG);             // [128] survivor's new class vector
   unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups that lost a maximum
   unsigned* sh_ctab = sh_gmask + 8;                                // [2048] same-slot check of a pass's inserts
+  u64* sh_stk = reinterpret_cast<u64*>(sh_ctab + 2048);            // [MN_X_TSTACK] nesting stack (ties)
   const int lane = threadIdx.x;
   const int C = P.C;
   const int B = 1 << X.Blog;
@@ -448,6 +514,14 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
 
   long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0, slow_inserts = 0;
   long long tied_steps = 0, tied_merges = 0;
+  // tie-conflict tracking: state of the previous launch
+  const long long steps0 = X.ctl->steps;
+  long long tied_conflicts = X.ctl->tied_conflicts;
+  int tdepth = X.ctl->tdepth, tpairs = X.ctl->tpairs, ttied = X.ctl->ttied;
+  bool track = X.ctl->ttrack != 0;
+  for (int i = lane; i < tdepth; i += 64) sh_stk[i] = X.tstack[i];
+  MN_X_LDS_SYNC();
+  unsigned ttopw = tdepth > 0 ? mn_x_te_word(sh_stk[tdepth - 1]) : 0u;
   unsigned long long bump = X.ctl->bump;
   int status = X.ctl->status < 0 || X.ctl->status == MN_X_HASH_FULL ? X.ctl->status : MN_X_RUNNING;
 #ifdef MN_X_STAMPS
@@ -491,10 +565,40 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     tied_steps += tied ? 1 : 0;
     MN_X_STAMP(2);
     const int x = mn_key_u(key), y = mn_key_v(key);
+    // ---- ties: this pop's place in the nesting of events ----
+    const unsigned long long ev64 = (unsigned long long)(steps0 + steps) + 1ull;
+    const unsigned ev = (unsigned)ev64;
+    if (track) {
+      while (tdepth > 0 && ttopw > gword) {
+        const int j = tdepth - 1 - lane;
+        const u64 e = (j >= 0) ? sh_stk[j] : 0ull;
+        const u64 below = (j >= 1) ? sh_stk[j - 1] : 0ull;
+        const bool rem = j >= 0 && mn_x_te_word(e) > gword;
+        const int cnt = __popcll(__ballot(rem));
+        tpairs -= __popcll(__ballot(rem && j >= 1 && mn_x_te_word(below) == mn_x_te_word(e)));
+        ttied -= __popcll(__ballot(rem && (e & 1ull)));
+        tdepth -= cnt;
+        ttopw = tdepth > 0 ? mn_x_te_word(sh_stk[tdepth - 1]) : 0u;
+        if (cnt < 64) break;
+      }
+      if (tdepth >= MN_X_TSTACK || ev64 >= 0x7FFFFFF0ull) {
+        tied_conflicts++;            // (cannot be followed any further: counted as a conflict, conservatively)
+        track = false;
+      } else {
+        if (tdepth > 0 && ttopw == gword) tpairs++;
+        if (lane == 0) sh_stk[tdepth] = ((u64)gword << 32) | ((u64)ev << 1) | (tied ? 1ull : 0ull);
+        tdepth++;
+        ttopw = gword;
+        ttied += tied ? 1 : 0;
+        MN_X_LDS_SYNC();
+      }
+    }
     // ---- re-score (segment.cc:560): both objects' state in one round trip ----
     const uint4 ox = *reinterpret_cast<const uint4*>(&X.obj[x]);
     const uint4 oy = *reinterpret_cast<const uint4*>(&X.obj[y]);
     const int capx = X.acap[x], capy = X.acap[y];
+    unsigned sx = 0u, sy = 0u;
+    if (track) { sx = X.ostamp[x]; sy = X.ostamp[y]; }
     float ax0 = 0.0f, ay0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f;
     if (lane < C) { ax0 = X.lp[(size_t)x * C + lane]; ay0 = X.lp[(size_t)y * C + lane]; }
     if (lane + 64 < C) { ax1 = X.lp[(size_t)x * C + lane + 64]; ay1 = X.lp[(size_t)y * C + lane + 64]; }
@@ -524,6 +628,13 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     const float f = mn_x_quotient(P, S * P.omf + cdl, nx, ny);
     const unsigned fw = mn_x_word(f);
     steps++;
+    if (track) {
+      if (lane == 0) { X.ostamp[x] = ev; X.ostamp[y] = ev; }
+      if (tpairs > 0 && (mn_x_tie_touch_uniform(sh_stk, tdepth, sx, lane) || mn_x_tie_touch_uniform(sh_stk, tdepth, sy, lane))) {
+        tied_conflicts++;
+        track = false;
+      }
+    }
     MN_X_STAMP(3);
     // merge when the fresh value is what the queue promised (segment.cc:561; the Python variant
     // merges on >=, segmenter.py:470)
@@ -609,8 +720,11 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       u64 kt = MN_EMPTY;
       float St = 0.0f;
       unsigned slot_t = 0;
+      unsigned oldw_t = 0u;
+      const bool rivals = track && ttied > 0;      // (only then can a touched record be a rival of an event on the stack)
       if (live) {
         const uint4 t = *reinterpret_cast<const uint4*>(&X.rec[e]);
+        if (rivals) oldw_t = X.leaf[e];
         kt = ((u64)t.y << 32) | (u64)t.x; St = __uint_as_float(t.z); slot_t = t.w;
       }
       live = live && kt != MN_EMPTY;
@@ -624,11 +738,13 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       float Su = 0.0f;
       unsigned u_rid = MN_X_INVALID;
       float v3[16];
+      unsigned s3 = 0u;
 #pragma unroll
       for (int q = 0; q < 16; q++) v3[q] = 0.0f;
       if (live) {
         const float* l3 = X.lp + (size_t)c3 * C;
         const uint4 o3 = *reinterpret_cast<const uint4*>(&X.obj[c3]);
+        if (track) { s3 = X.ostamp[c3]; X.ostamp[c3] = ev; }
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (4 * q < C) {     // (16-byte loads; what lies behind the object's C terms is read and ignored)
@@ -658,6 +774,14 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       float Sn = St;
       const bool fold = live && found >= 0;
       const bool adopt = live && found < 0;
+      if (track) {
+        bool conf = live && tpairs > 0 && mn_x_tie_touch_lane(sh_stk, tdepth, s3);
+        if (rivals) {
+          const unsigned oldw_u = fold ? X.leaf[u_rid] : 0u;
+          conf = conf || (live && (mn_x_tie_rival_lane(sh_stk, tdepth, oldw_t) || mn_x_tie_rival_lane(sh_stk, tdepth, oldw_u)));
+        }
+        if (__ballot(conf)) { tied_conflicts++; track = false; }
+      }
       if (fold) {
         // the survivor already has a record with the third object: add (:690-692), retire this one (:694)
         tr = u_rid;
@@ -683,22 +807,29 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
           X.hs[slot_t].key = MN_X_HEMPTY;
           X.arena[(size_t)pa + la + __popcll(am & ((1ull << lane) - 1ull))] = e;
         }
+        // Every lane records its slot in X.rec[e] BEFORE a later slow insert can run: a slow insert may move
+        // an occupant of a full bucket -- possibly a record placed a moment ago by a lane of this very pass --
+        // to its other bucket and then corrects rec[occupant].slot; a record written afterwards would
+        // bring the old slot back and a later delete would free another pair's entry.
         if (adopt && !clash) {
           XSlot ns; ns.key = key2; ns.rid = e; ns.S = St;
           *reinterpret_cast<uint4*>(&X.hs[freeslot]) = *reinterpret_cast<const uint4*>(&ns);
+          XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
+          *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
         }
         u64 cm = __ballot(clash);
         while (cm) {
           const int l = __ffsll((long long)cm) - 1;
           cm &= cm - 1ull;
           slow_inserts++;
-          if (lane == l) nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St);
+          if (lane == l) {
+            nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St, (X.dbg & 1) != 0);
+            XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
+            *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
+          }
+          MN_X_MEM_SYNC();
         }
         if (__ballot(adopt && nslot == MN_X_INVALID)) { status = MN_X_HASH_FULL; break; }
-        if (adopt) {
-          XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
-          *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
-        }
       }
       MN_X_STAMP(9);
       la += __popcll(am);
@@ -791,6 +922,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     MN_X_STAMP(11);
   }
 
+  for (int i = lane; i < tdepth; i += 64) X.tstack[i] = sh_stk[i];
   if (lane == 0) {
     XCtl* c = X.ctl;
 #ifdef MN_X_STAMPS
@@ -800,8 +932,32 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     c->steps += steps; c->merges += merges; c->rescans += rescans; c->reallocs += reallocs;
     c->folded += folded; c->adopted += adopted; c->slow_inserts += slow_inserts;
     c->tied_steps += tied_steps; c->tied_merges += tied_merges;
+    c->tied_conflicts = tied_conflicts; c->tdepth = tdepth; c->tpairs = tpairs; c->ttied = ttied;
+    c->ttrack = track ? 1 : 0;
     c->bump = bump;
   }
+}
+
+// Tests (MN_X_CHECK_SLOTS): every live record's slot holds its key and id, every occupied slot names a live
+// record with that key that points back at it (a stale slot index would free another pair's entry later).
+__global__ __launch_bounds__(256) void mn_x_check_slots(XState X) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = 0;
+  if (i < X.NL) {
+    const XRec R = X.rec[i];
+    if (R.key != MN_EMPTY) {
+      if (R.slot == MN_X_INVALID || R.slot >= (X.bmask + 1u) * 4u) bad++;
+      else { const XSlot s = X.hs[R.slot]; if (s.key != R.key || s.rid != (unsigned)i || s.S != R.S) bad++; }
+    }
+  }
+  if (i < ((size_t)X.bmask + 1) * 4) {
+    const XSlot s = X.hs[i];
+    if (s.key != MN_X_HEMPTY) {
+      if (s.rid >= X.NL) bad++;
+      else { const XRec R = X.rec[s.rid]; if (R.key != s.key || R.slot != (unsigned)i) bad++; }
+    }
+  }
+  if (bad) atomicAdd((unsigned long long*)&X.ctl->slot_errors, (unsigned long long)bad);
 }
 
 // Phase A as the engine holds it, in the layout of the oracle's phase-A export (tests): per (offset, source

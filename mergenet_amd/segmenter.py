@@ -37,7 +37,7 @@ MN_DEBUG_CLUSTERS = 512           # general rounds: contract order-free clusters
 MN_DEBUG_OLD_EXACT = 256          # MN_MODE_EXACT by the small-list finisher instead of the exact engine
 MN_PROVE_ALWAYS, MN_PROVE_BY_MODE, MN_PROVE_NEVER = 1, 0, -1   # mn_options.require_proof
 MN_TIES_DEFAULT, MN_TIES_REFERENCE, MN_TIES_LOWEST_ID = 0, 1, 2   # mn_options.tie_order
-MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL = 0, 1, 2
+MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL, MN_PROOF_SEQUENTIAL_TIES = 0, 1, 2, 3   # mn_stats.proof
 
 SegmenterOptions = namedtuple("SegmenterOptions",
                               ["same_different_bias", "object_merge_factor", "merge_logprob_bias"])
@@ -69,7 +69,7 @@ class MnStats(ctypes.Structure):
                 ("ms_cc_label", ctypes.c_float), ("ms_cc_sums", ctypes.c_float),
                 ("ms_cc_edges", ctypes.c_float), ("ms_cc_cross", ctypes.c_float),
                 ("proof", ctypes.c_int), ("cores_condemned", ctypes.c_int), ("tied_steps", ctypes.c_int), ("tied_merges", ctypes.c_int),
-                ("tie_order_used", ctypes.c_int), ("reserved_i", ctypes.c_int)]
+                ("tie_order_used", ctypes.c_int), ("tied_conflicts", ctypes.c_int)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_i"}

@@ -137,6 +137,11 @@ def cseg_specs(big: bool):
         specs.append(dict(name="cseg_blur4_128x256_s%d" % sd, kind="blur", H=128, W=256, C=9, offsets=[40, 10],
                           seed=sd, radius=4, noise=0.05, opts=(0.0, 1.0, 0.03)))
     if big:
+        # (round 4) a tie-decided vector ABOVE MN_TIE_LIMIT_RECORDS (1.25 M records): the exact engine's own rule
+        # (lowest record id) differs from the reference here (found with tests/tools/tie_search.py: CPU model of
+        # the engine's semantics beside the oracle)
+        specs.append(dict(name="cseg_blur4_256x512_s5200", kind="blur", H=256, W=512, C=9, offsets=[40, 10],
+                          seed=5200, radius=4, noise=0.05, opts=(0.0, 1.0, 0.03)))
         specs.append(dict(name="cseg_blur_256x512_r2", kind="blur", H=256, W=512, C=9,
                           offsets=[40, 10], seed=8000, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
         for sd in (6400, 6408):

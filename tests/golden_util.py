@@ -65,3 +65,13 @@ def load(name):
     assert h.hexdigest() == str(z["sha256"]), "generator drifted: inputs no longer match the fixture"
     return dict(spec=spec, offsets=offs, class_probs=cp, sameness_probs=sp, mask=z["mask"],
                 object_class=[int(c) for c in z["object_class"]], error=str(z["error"]))
+
+
+def sequential_proof(st):
+    """What mn_stats.proof must say of an exact-engine result: 2 (the reference's order, nothing left to a tie
+    rule) when every pop was forced, no tied pop had a conflict, or the reference's own order among equals was
+    run; 3 otherwise."""
+    from mergenet_amd import segmenter as seg
+    forced = (st["tied_steps"] == 0 or st["tie_order_used"] == seg.MN_TIES_REFERENCE or
+              st.get("tied_conflicts", 1) == 0)
+    return seg.MN_PROOF_SEQUENTIAL if forced else seg.MN_PROOF_SEQUENTIAL_TIES

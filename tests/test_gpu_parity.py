@@ -472,7 +472,7 @@ def test_auto_mode_picks_components_for_large_images(oracle):
     assert st["mode_used"] == seg.MN_MODE_COMPONENTS and st["proof"] == seg.MN_PROOF_NONE
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
     mask, classes, part, st = _run(g, seg.MN_MODE_AUTO)      # default: redone in the sequential order
-    assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] == seg.MN_PROOF_SEQUENTIAL
+    assert st["mode_used"] == seg.MN_MODE_EXACT and st["proof"] == gu.sequential_proof(st)
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
 
 

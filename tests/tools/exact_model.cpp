@@ -1,0 +1,210 @@
+// exact_model.cpp -- TEST / DESIGN TOOL, NOT PRODUCT CODE.
+//
+// CPU model of the exact engine's SEMANTICS (mergenet_amd/csrc/mn_kernels_exact.h): the reference's lazy
+// greedy (utils/csegment/segment.cc:539-573, 602-727) with its float32 arithmetic, but with the queue as
+// "the stored priority of every live record, if >= 0" under a TOTAL order: priority, then record id
+// (= pixel * O + offset index, the creation order of segment.cc:209-231).  Uses the C library's logf /
+// log, so its numbers are the reference's; differs from oracle/csegment_oracle.cpp only in the order
+// among bit-equal priorities (the oracle keeps std::priority_queue's heap order).
+//
+// Used to (a) find inputs whose result the tie rule decides, without a GPU (tests/golden/make_golden.py
+// --tie-search), (b) measure the structure of the event sequence (nesting depth, super-events, tie
+// conflicts) that DESIGN.md section 4.2 / 5 quotes, (c) check the tie-conflict criterion of the engine
+// (stats.tied_conflicts) against an independent implementation.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC exact_model.cpp -o libexact_model.so
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Key {
+  float p; int r;
+  bool operator<(const Key& o) const { return p > o.p || (p == o.p && r < o.r); }   // largest priority, lowest id first
+};
+
+struct Model {
+  int C, O, W, H, N;
+  float omf, bias;
+  std::vector<float> lp;
+  std::vector<int> ocls, osize, parent;
+  std::vector<std::unordered_map<int, int>> adj;      // other endpoint -> record
+  std::vector<int> r1, r2;                            // endpoints (r1 < r2), r2 = -1: dead
+  std::vector<float> S, prio;                         // log-odds sum, stored priority (NaN-free; < 0: not queued)
+  std::set<Key> q;
+  long long steps = 0, merges = 0, tied_steps = 0, tied_merges = 0;
+  // ---- tie-conflict criterion ----
+  // Events form a forest by nesting: event j hangs under the last earlier event i with word(i) <= word(j)
+  // such that everything between them is above word(i) (the suffix minima of the popped priorities).
+  // Two events with EQUAL priorities that are siblings in that forest are ordered by the tie rule; their
+  // subtrees commute iff they touch disjoint objects.  stamp[o] = index of the last event that touched o.
+  std::vector<long long> stamp;
+  std::vector<std::pair<float, long long>> stk;        // suffix minima: (priority, event index), priorities non-decreasing
+  long long tied_pairs_on_stack = 0;                   // adjacent stack entries with equal priority
+  long long tied_conflicts = 0;
+  long long max_depth = 0;
+  int track = 0;
+
+  float score(int a, int b, float s, int* mc) const {
+    float cdl = 0.0f;
+    int m = ocls[a];
+    if (ocls[a] != ocls[b]) {
+      const float* la = &lp[(size_t)a * C];
+      const float* lb = &lp[(size_t)b * C];
+      int best = 0;
+      float bestv = la[0] + lb[0];
+      for (int c = 1; c < C; c++) { const float v = la[c] + lb[c]; if (v > bestv) { bestv = v; best = c; } }
+      m = best;
+      cdl = bestv - la[ocls[a]] - lb[ocls[b]];
+    }
+    *mc = m;
+    const size_t den = (size_t)osize[a] + (size_t)osize[b];
+    return (s * omf + cdl) / den + bias;
+  }
+
+  void store(int r, float f) {
+    if (prio[r] >= 0.0f) q.erase(Key{prio[r], r});
+    prio[r] = f;
+    if (f >= 0.0f) q.insert(Key{f, r});
+  }
+
+  // touch of object o by event `ev` (popped priority pw): conflict iff the last toucher lies in the subtree
+  // of a tied sibling of one of ev's ancestors-or-self
+  void touch(int o, long long ev) {
+    if (!track) return;
+    const long long s = stamp[o];
+    stamp[o] = ev;
+    if (s == 0 || tied_pairs_on_stack == 0) return;
+    // first stack entry with index > s
+    size_t lo = 0, hi = stk.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (stk[mid].second > s) hi = mid; else lo = mid + 1; }
+    if (lo == stk.size() || lo == 0) return;           // (s is the current event itself, or older than the whole stack)
+    if (stk[lo - 1].first == stk[lo].first) tied_conflicts++;
+  }
+
+  void sibling_check(float old) {
+    if (!track || old < 0.0f) return;
+    size_t lo = 0, hi = stk.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (stk[mid].first >= old) hi = mid; else lo = mid + 1; }
+    if (lo < stk.size() && stk[lo].first == old) tied_conflicts++;
+  }
+
+  void run(const float* cls_p, const float* same_p, const int* offs) {
+    N = W * H;
+    lp.resize((size_t)N * C); ocls.resize(N); osize.assign(N, 1); parent.resize(N); adj.resize(N);
+    stamp.assign(N, 0);
+    for (int p = 0; p < N; p++) {
+      float* l = &lp[(size_t)p * C];
+      int best = 0;
+      for (int c = 0; c < C; c++) { l[c] = logf(cls_p[(size_t)c * N + p]); if (l[c] > l[best]) best = c; }
+      ocls[p] = best; parent[p] = p;
+    }
+    const size_t NL = (size_t)N * O;
+    r1.assign(NL, -1); r2.assign(NL, -1); S.assign(NL, 0.0f); prio.assign(NL, -1.0f);
+    for (int p = 0; p < N; p++) {
+      const int row = p / W, col = p % W;
+      for (int k = 0; k < O; k++) {
+        const int rr = row + offs[2 * k], cc = col + offs[2 * k + 1];
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+        const int qx = rr * W + cc;
+        const float sp = same_p[(size_t)k * N + p];
+        const float diff = (float)log(1.0 - (double)sp);
+        const float same = logf(sp);
+        const int r = p * O + k;
+        r1[r] = std::min(p, qx); r2[r] = std::max(p, qx);
+        S[r] = same - diff;
+        adj[p][qx] = r; adj[qx][p] = r;
+        int mc;
+        const float f = score(r1[r], r2[r], S[r], &mc);
+        prio[r] = f;
+        if (f >= 0.0f) q.insert(Key{f, r});
+      }
+    }
+    long long ev = 0;
+    while (!q.empty()) {
+      const Key top = *q.begin();
+      const int r = top.r;
+      // tied: a second live record with the bit-equal stored priority
+      bool tied = false;
+      { auto it = q.begin(); ++it; if (it != q.end() && it->p == top.p) tied = true; }
+      steps++; ev++;
+      tied_steps += tied;
+      if (track) {
+        // suffix minima of the popped priorities (non-strict): entries above the new one leave
+        while (!stk.empty() && stk.back().first > top.p) {
+          if (stk.size() >= 2 && stk[stk.size() - 2].first == stk.back().first) tied_pairs_on_stack--;
+          stk.pop_back();
+        }
+        if (!stk.empty() && stk.back().first == top.p) tied_pairs_on_stack++;
+        stk.push_back(std::make_pair(top.p, ev));
+        if ((long long)stk.size() > max_depth) max_depth = (long long)stk.size();
+      }
+      const int x = r1[r], y = r2[r];
+      int mc;
+      const float f = score(x, y, S[r], &mc);
+      touch(x, ev); touch(y, ev);
+      if (f != top.p) { store(r, f); continue; }
+      // merge
+      int a = x, b = y;
+      if (osize[a] < osize[b]) std::swap(a, b);
+      merges++; tied_merges += tied;
+      q.erase(top); prio[r] = -1.0f; r2[r] = -1;
+      ocls[a] = mc;
+      osize[a] += osize[b];
+      float* la = &lp[(size_t)a * C];
+      const float* lb = &lp[(size_t)b * C];
+      for (int c = 0; c < C; c++) la[c] += lb[c];
+      adj[a].erase(b); adj[b].erase(a);
+      for (auto& kv : adj[b]) {
+        const int c3 = kv.first, t = kv.second;
+        touch(c3, ev);
+        adj[c3].erase(b);
+        // a record modified (or retired) while its stored priority equals that of an event on the stack -- an
+        // ancestor of this event or the event itself: it is a tied sibling whose turn might have come first
+        auto hit = adj[a].find(c3);
+        int tr;
+        if (hit != adj[a].end()) {
+          tr = hit->second;
+          sibling_check(prio[t]);
+          sibling_check(prio[tr]);
+          S[tr] += S[t];
+          if (prio[t] >= 0.0f) q.erase(Key{prio[t], t});
+          prio[t] = -1.0f; r2[t] = -1;
+        } else {
+          tr = t;
+          sibling_check(prio[t]);
+          r1[t] = std::min(a, c3); r2[t] = std::max(a, c3);
+          adj[a][c3] = t; adj[c3][a] = t;
+        }
+        int m2;
+        store(tr, score(r1[tr], r2[tr], S[tr], &m2));
+      }
+      std::unordered_map<int, int>().swap(adj[b]);
+      parent[b] = a;
+    }
+  }
+
+  int root(int p) { while (parent[p] != p) p = parent[p]; return p; }
+};
+
+}  // namespace
+
+extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, int C, int O, int W, int H,
+                               const int* offs, float omf, float bias, int track, int* partition, int* obj_class,
+                               double* stats) {
+  Model m;
+  m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
+  m.run(class_pred, adj_pred, offs);
+  for (int p = 0; p < W * H; p++) { const int o = m.root(p); partition[p] = o; obj_class[p] = m.ocls[o]; }
+  if (stats) {
+    stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
+    stats[3] = (double)m.tied_merges; stats[4] = (double)m.tied_conflicts; stats[5] = (double)m.max_depth;
+  }
+  return 0;
+}
