@@ -128,44 +128,90 @@ def exact_engine_sample(seg, synth, offs, device):
         same = bool(ck.masks_equivalent(mask.cpu().numpy(), got, z["mask"], [int(c) for c in z["object_class"]]))
         out.append({"image": name, "seconds": round(dt, 3), "value": round(hh * ww / dt / 1e6, 4), "unit": "Mpixel/s",
                     "steps": st["finisher_steps"], "merges": st["merges"], "proof": st["proof"],
-                    "tied_steps": st["tied_steps"], "tie_order_used": st["tie_order_used"],
-                    "equals_reference": same})
+                    "tied_steps": st["tied_steps"], "tied_conflicts": st["tied_conflicts"],
+                    "tie_order_used": st["tie_order_used"], "equals_reference": same})
         m.close()
-    # the loop is one wavefront per image: a batch of images in ONE launch, a workgroup each
-    # (mn_segment_exact_batch), multiplies the rate -- the reference scales the same way, by processes (--num-jobs)
-    pool_out = None
-    try:
-        count = 192
-        names = ["cseg_synth_512x1024_s1000", "cseg_synth_512x1024_s1001", "cseg_synth_512x1024_s1002"]
-        imgs = []
-        for nm in names:
-            z = np.load(os.path.join(ROOT, "tests", "golden", nm + ".npz"))
-            spec = json.loads(str(z["spec"]))
-            im = synth.synth_v1(512, 1024, C, offs, spec["seed"])
-            imgs.append((torch.from_numpy(im.class_probs).cuda(device), torch.from_numpy(im.sameness_probs).cuda(device), z))
-        batch = seg.ExactBatch(512, 1024, C, len(offs), count, device=device)
-        o = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
-                                merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_EXACT, clip_inputs=1)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        res = batch.segment([imgs[i % 3][0] for i in range(count)], [imgs[i % 3][1] for i in range(count)], offs, o)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        same = True
-        for i, (mask, table, _, st) in enumerate(res):
-            z = imgs[i % 3][2]
-            got = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
-            same &= bool(ck.masks_equivalent(mask.cpu().numpy(), got, z["mask"], [int(c) for c in z["object_class"]]))
-        batch.close()
-        pool_out = {"images_per_launch": count, "size": "512x1024", "seconds": round(dt, 3),
-                    "value": round(count * 512 * 1024 / dt / 1e6, 4), "unit": "Mpixel/s", "all_equal_reference": same,
-                    "note": "includes allocating the %d workspaces" % count}
-    except Exception as e:                                    # noqa: BLE001 -- a side measurement must not fail the line
-        pool_out = {"error": repr(e)}
+    pool_out = None            # (the batch measurement moved to `default_mode`, at the benchmark's own size)
     return {"what": "MN_MODE_EXACT: the reference's sequential order (segment.cc:539-727) with its float32 "
                     "arithmetic, one wavefront per image; what AUTO falls back to when the fast path cannot "
                     "certify its answer.  The reference itself: 84 s at 512x1024, 12-15 s at 256x512 (BASELINE.md)",
             "samples": out, "batch": pool_out}
+
+
+def default_mode_block(seg, pool_images, seeds, offs, device, max_batch):
+    """The PROVEN path on the benchmark's own images (configs[1], 1024x2048): the library's default options
+    (MN_MODE_AUTO, require_proof = 0).  The speculative attempt cannot certify these images (second-phase
+    merges), so each is redone by the exact engine -- the reference's sequential order itself.  (a) ONE image
+    through mn_segment_device with default options: the latency of the default call; (b) ONE
+    mn_segment_exact_batch of as many images as fit (a workgroup per image in one launch: how the sequential
+    order gets throughput; the reference scales the same way, by processes).  Every result is compared with
+    the reference's own output (golden vectors)."""
+    import numpy as np
+    import torch
+    from mergenet_amd import labels as ck
+    goldens = []
+    for sd in seeds:
+        gname = "cseg_synth_1024x2048_cfg2.npz" if sd == 1000 else "cseg_synth_1024x2048_s%d.npz" % sd
+        path = os.path.join(ROOT, "tests", "golden", gname)
+        goldens.append(np.load(path) if os.path.exists(path) else None)
+
+    def equal(mask, table, st, z):
+        if z is None:
+            return None
+        got = [int(c) for c in table.cpu().numpy()[: st["num_instances"]]]
+        return bool(ck.masks_equivalent(mask.cpu().numpy(), got, z["mask"], [int(c) for c in z["object_class"]]))
+
+    O = len(offs)
+    o_default = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
+                                    merge_logprob_bias=OPTS[2], clip_inputs=1)          # mode AUTO, require_proof 0
+    m = seg.Merger(H, W, C, O, device=device)
+    cp, sp = pool_images[0]
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    mask, table, _, st = m.segment(cp, sp, offs, o_default)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    single = {"seconds": round(dt, 3), "value": round(H * W / dt / 1e6, 4), "unit": "Mpixel/s",
+              "mode_used": {1: "exact", 2: "rounds", 3: "components"}.get(st["mode_used"]), "proof": st["proof"],
+              "steps": st["finisher_steps"], "merges": st["merges"], "tied_steps": st["tied_steps"],
+              "tied_conflicts": st["tied_conflicts"], "tie_order_used": st["tie_order_used"],
+              "equals_reference": equal(mask, table, st, goldens[0]),
+              "how": "one mn_segment_device call with mn_default_options (AUTO): speculative attempt, certificate "
+                     "fails, exact engine"}
+    per_image = m.workspace_bytes() + 3 * 4 * H * W
+    m.close()
+    del mask, table
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info(device)
+    count = int(max(1, min(max_batch, (0.90 * free) // per_image)))
+    batch_out = None
+    try:
+        batch = seg.ExactBatch(H, W, C, O, count, device=device)
+        o_exact = seg.default_options(same_different_bias=OPTS[0], object_merge_factor=OPTS[1],
+                                      merge_logprob_bias=OPTS[2], mode=seg.MN_MODE_EXACT, clip_inputs=1)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        res = batch.segment([pool_images[i % len(pool_images)][0] for i in range(count)],
+                            [pool_images[i % len(pool_images)][1] for i in range(count)], offs, o_exact)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        eq = [equal(mk, tb, s_, goldens[i % len(pool_images)]) for i, (mk, tb, _, s_) in enumerate(res)]
+        proofs = sorted({r[3]["proof"] for r in res})
+        batch.close()
+        batch_out = {"images_per_launch": count, "seconds": round(dt, 3),
+                     "value": round(count * H * W / dt / 1e6, 4), "unit": "Mpixel/s",
+                     "proof": proofs, "tied_conflicts_any": bool(any(r[3]["tied_conflicts"] > 0 for r in res)),
+                     "all_equal_reference": bool(all(e for e in eq if e is not None)) if any(e is not None for e in eq) else None,
+                     "workspace_bytes_per_image": int(per_image),
+                     "how": "one mn_segment_exact_batch launch, a workgroup per image; seconds include allocating "
+                            "and setting up the %d workspaces" % count}
+    except Exception as e:                                    # noqa: BLE001 -- a side measurement must not fail the line
+        batch_out = {"error": repr(e)}
+    return {"what": "the library's DEFAULT behaviour on the timed workload's own images (1024x2048, the pool of this "
+                    "rank): results are the reference's sequential order (proof 2: nothing left to a tie rule; 3: "
+                    "equal priorities popped in creation order where the reference pops by heap position -- these "
+                    "maps clip a third of their values to 0.99, so ties abound)",
+            "single_image": single, "batch": batch_out}
 
 
 def main():
@@ -176,7 +222,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
-    ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine sample (about 8 s)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine samples at smaller sizes")
+    ap.add_argument("--no-default-mode", action="store_true",
+                    help="skip the default-mode (proven path) measurement at 1024x2048: one image + one batch")
+    ap.add_argument("--default-batch", type=int, default=64,
+                    help="most images in the default-mode batch launch (fewer if they do not fit in memory)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="drop the per-kernel HIP events inside the library (roofline then reads 0)")
@@ -447,6 +497,27 @@ def main():
     if rank == 0 and world == 1 and not args.no_exact:
         exact = exact_engine_sample(seg, synth, offs, local_rank)
 
+    # the proven path (library defaults) on this rank's own pool, outside the timed region; the ring's
+    # contexts are released first (the batch takes what memory there is)
+    default_mode = None
+    if not args.no_default_mode:
+        for mg in mergers_ring[1:]:
+            mg.close()
+        default_mode = default_mode_block(seg, pool_images, seeds, offs, local_rank, args.default_batch)
+        if world > 1:
+            # whole-job figures: the ranks' batches run side by side
+            b = default_mode.get("batch") or {}
+            t = torch.tensor([float(b.get("seconds", 0.0)), float(b.get("images_per_launch", 0)),
+                              float(default_mode["single_image"]["seconds"]),
+                              1.0 if b.get("all_equal_reference") else 0.0], dtype=torch.float64, device=dev)
+            tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone(); dist.all_reduce(tsum)
+            default_mode["all_ranks"] = {
+                "batch_images": int(tsum[1].item()), "batch_seconds_max": round(float(tmax[0].item()), 3),
+                "batch_value": round(float(tsum[1].item()) * H * W / max(float(tmax[0].item()), 1e-9) / 1e6, 4),
+                "unit": "Mpixel/s", "single_image_seconds_max": round(float(tmax[2].item()), 3),
+                "ranks_all_equal_reference": int(tsum[3].item())}
+
     if rank == 0:
         plane_bytes = 4.0 * H * W
         pmc = {}
@@ -497,7 +568,7 @@ def main():
                     "why_this_kernel": "the one HBM-streaming kernel of the timed path: it reads every input "
                                        "plane (class + sameness) exactly once"}
         out = {
-            "metric": "merged Mpixels/sec at 1024x2048",
+            "metric": "merged Mpixels/sec at 1024x2048 (speculative fast path; proven path: value_proven_path)",
             "value": round(world * args.steps * H * W / elapsed / 1e6, 4),
             "unit": "Mpixel/s",
             "n_gpus": world,
@@ -567,6 +638,13 @@ def main():
                 "algorithmic_bytes": (C + O) * plane_bytes, "avg_launch_ms": round(sc_ms, 5),
                 "whole_image_ms_rounds_mode": round(general["ms_total"], 3),
                 "note": "measured live with the same HIP events, outside the timed steps"}
+        if default_mode is not None:
+            out["default_mode"] = default_mode
+            sb = default_mode.get("all_ranks") or default_mode.get("batch") or {}
+            out["value_proven_path"] = sb.get("batch_value", sb.get("value"))
+            out["value_is"] = ("the SPECULATIVE fast path (require_proof = -1; equality with the reference measured, "
+                               "not proven: id_match); the same images through the library's default (proven) mode: "
+                               "default_mode / value_proven_path")
         if exact is not None:
             out["exact_engine"] = exact
         if world == 1 and not args.no_cpu_baseline:

@@ -57,9 +57,8 @@ enum mn_mode {
                             else EXACT (require_proof = -1: keep the fast path's unproven answer)   */
   MN_MODE_EXACT = 1,     /* the reference's sequential lazy-greedy order itself, any image size: the
                             exact engine (mn_kernels_exact.h) -- float32 state and operation order of
-                            segment.cc, glibc's logf restated bit for bit, pop = block-max queue in
-                            LDS, per-object adjacency, pair table; ~1.5 s at 256x512, ~6 s at 512x1024
-                            (the reference: 12 s and 84 s)                                         */
+                            segment.cc, glibc's logf / expf restated bit for bit, pop = block-max queue in
+                            LDS, per-object adjacency, pair table (seconds per image: DESIGN.md section 6) */
   MN_MODE_ROUNDS = 2,    /* parallel rounds + sequential finisher + certificate                  */
   MN_MODE_COMPONENTS = 3 /* sign-separable inputs: phase 1 of the merge (provably order-
                             independent there) by one union-find sweep over the positive edges,
@@ -110,8 +109,7 @@ typedef struct mn_options {
   int debug_flags;             /* bit 0: use the generic edge pass where the fast form would run (tests
                                   compare the two); bit 1: no per-kernel timestamps in components mode
                                   (ms_cc_* stay 0; each is an event on the caller's stream); bit 2:
-                                  general rounds from single pixels instead of from the cores; bit 3: no
-                                  contraction of order-free clusters in the general rounds (overrides bit 9); bit 4: only
+                                  general rounds from single pixels instead of from the cores; bit 4: only
                                   the sweep is timed (ms_cc_edges; the other ms_* stay 0) -- an event
                                   costs the host ~3.5 us to record and ~8 us to read; bit 5 (with
                                   bit 4): replay -- when mn_segment_launch is called again with the
@@ -120,12 +118,8 @@ typedef struct mn_options {
                                   (from the third): a loop over images through fixed buffers; bit 7:
                                   time the sweep with an event packet before and behind it instead
                                   of start/stop events on its own dispatch (round 2's first form:
-                                  measures dispatch gap + kernel); bit 9: the general rounds contract order-free
-                                  clusters of objects (round 2's default; 2.5 instead of ~12 ms on a
-                                  separable 1024x2048 map, but the second phase then starts from fresh
-                                  instead of stale priorities: off by default); bit 8: MN_MODE_EXACT by the small-list
-                                  finisher (one workgroup, O(records) arg-max per step, fixed-point sums)
-                                  instead of the exact engine -- kept for comparison                */
+                                  measures dispatch gap + kernel).  (Round 4 removed the opt-in engines
+                                  that were measured slower or known to deviate: bits 3, 8-13.)          */
   int require_proof;           /* what happens to a result that is not PROVEN equal to the reference's
                                   sequential order (stats.proof == 0): 1 = it is redone in MN_MODE_EXACT,
                                   whatever mode was asked for, and -- if that run chose among bit-equal

@@ -21,7 +21,6 @@
 #include "mn_kernels_prepare.h"
 #include "mn_kernels_cc.h"
 #include "mn_kernels_tail.h"
-#include "mn_kernels_oc.h"
 #include "mn_kernels_exact.h"
 #include "mn_kernels_reforder.h"
 
@@ -723,44 +722,6 @@ static int build_list(mn_context* c, const ImgParams& P, hipStream_t st, size_t 
   return MN_OK;
 }
 
-// Contraction of the order-free clusters of objects of a record list (mn_kernels_oc.h): object
-// state updated, members marked in matched[]; the caller rebuilds the list if `merged` comes back set.
-static int contract_clusters(mn_context* c, const ImgParams& P, hipStream_t st, RecList L, int R,
-                             i64 tau, bool* merged) {
-  ObjState S = obj_state(c);
-  int* up = c->root;                    // free between the cores and the output stage
-  unsigned char* bad = c->pruned;
-  const int N = P.N;
-  FillList f;
-  f.add(c->matched, (size_t)N, 0);
-  f.add(&c->cnt->any_selected, sizeof(int), 0);
-  f.launch(st);
-  const dim3 g(grid_for(R, 256)), b(256), go(grid_for(N, 256));
-  hipLaunchKernelGGL(mn_oc_init, go, b, 0, st, N, (const int*)c->parent, up, bad);
-  if (R > (1 << 16)) {                  // a sample first, then everything against flat labels
-    hipLaunchKernelGGL(mn_oc_link, dim3(grid_for((R + 7) / 8, 256)), b, 0, st, S, L, R, tau, up, 8);
-    hipLaunchKernelGGL(mn_oc_flatten, go, b, 0, st, N, (const int*)c->parent, up);
-  }
-  hipLaunchKernelGGL(mn_oc_link, g, b, 0, st, S, L, R, tau, up, 1);
-  hipLaunchKernelGGL(mn_oc_flatten, go, b, 0, st, N, (const int*)c->parent, up);
-  hipLaunchKernelGGL(mn_oc_check, g, b, 0, st, S, L, R, tau, (const int*)up, bad);
-  hipLaunchKernelGGL(mn_oc_clear, go, b, 0, st, P, (const int*)c->parent, (const int*)up,
-                     (const unsigned char*)bad, c->lp_acc);
-  const size_t lds = (size_t)MN_CC_SUM_SLOTS * (P.C + 1) * sizeof(u64);
-  if (lds > c->oc_lds) {             // (127 classes: 64 KiB of table, more than a kernel gets unasked)
-    MN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mn_oc_gather),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->oc_lds = lds;
-  }
-  hipLaunchKernelGGL(mn_oc_gather, dim3(grid_for(N, MN_OC_THREADS)), dim3(MN_OC_THREADS), lds, st, P, S,
-                     (const int*)up, (const unsigned char*)bad, c->lp_acc, c->matched, c->cnt);
-  hipLaunchKernelGGL(mn_oc_finish, go, b, 0, st, P, S, (const i64*)c->lp_acc, (const unsigned char*)c->matched);
-  MN_HIP(hipGetLastError());
-  if (read_counters(c, st) != MN_OK) return MN_ERR_NO_DEVICE;
-  *merged = c->h_cnt->any_selected != 0;
-  return MN_OK;
-}
-
 // Plane stride of the sweep's per-lane class log-products (N / 4 ints used per plane, inside the [C][N] float
 // buffer of the class sums): an odd multiple of 256 B, so that the C planes a lane writes one after the other
 // do not all start on the same memory channel (a stride of N ints is a power of two at 1024 x 2048).
@@ -837,7 +798,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   const dim3 tiles((P.W + 63) / 64, (P.H + MN_CC_TILE_ROWS - 1) / MN_CC_TILE_ROWS);
   // the sweep takes 4 pixels per lane whenever the planes stay 16-byte aligned (N % 4 == 0): with
   // W % 4 != 0 one lane per row runs over the row's end (mn_cc_sign: `straddle`)
-  const bool sweep4 = (N & 3) == 0;
+  // (W >= 4: a straddling lane's four pixels then span at most two rows, which is what mn_cc_sign assumes)
+  const bool sweep4 = (N & 3) == 0 && P.W >= 4;
   const size_t sign_blocks = grid_for((size_t)(sweep4 ? N / 4 : N), MN_CC_SIGN_THREADS);
   c->cc_sign_blocks = (int)(sign_blocks * (MN_CC_SIGN_THREADS / 64));       // (waves: one partial sum each)
   // class range of the components: `root` and `mapbuf` are free until the output stage
@@ -852,18 +814,6 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
   if (sweep4) launch_cc_px<4>(c, P, st, 0u, false, fused_cls, nullptr, nullptr, lean_cls);
   else launch_cc_px<1>(c, P, st, 0u, false);
   if (!few_events && !c->ext_events) MN_HIP(hipEventRecord(c->ev[10], st));
-  // debug_flags bit 11: fork right behind the sweep -- the labelling too runs on the side stream, beside
-  // the next images' sweeps (the caller's stream then carries the sweeps alone)
-  const bool early_fork = fork_before_sums && (c->debug_flags & 2048) && !c->replay.capturing && !cores;
-  if (early_fork) {
-    if (c->ext_events) {
-      MN_HIP(hipStreamWaitEvent(c->side, c->ev[10], 0));           // (the sweep's own stop event)
-    } else {
-      MN_HIP(hipEventRecord(c->ev_fork, st));
-      MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    }
-    st = c->side;
-  }
   // cores (first step of the general rounds): the labelling runs on the edges between clean pixels
   const unsigned* lbits = c->cc_bits;
   unsigned kshort = 0u;
@@ -891,29 +841,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     st = c->replay.cap;
   }
   unsigned kmask = P.O >= 32 ? 0xFFFFFFFFu : ((1u << P.O) - 1u);
-  const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing && !early_fork;
-  bool fork_by_hook = false, mid_fork = false;
-  if (c->debug_flags & 1024) {
-    // (opt-in, slower so far: 8.7 + 25 + 9 + 30 us against 59 us) labelling by row runs in 16 x 256 tiles (mn_cc_tiles2 / mn_cc_link / mn_cc_flat_roots)
-    const unsigned lanes = (unsigned)(((P.W + 3) >> 2) * P.H);
-    const dim3 tiles2((P.W + MN_T2_COLS - 1) / MN_T2_COLS, (P.H + MN_T2_ROWS - 1) / MN_T2_ROWS);
-    int* dbg = getenv("MN_TRACE_LABEL") ? c->scalars + 10 : nullptr;     // [10..12]: unions asked for by the stages
-    hipLaunchKernelGGL(mn_cc_tiles2, tiles2, dim3(MN_T2_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv);
-    if (kh >= 0 || kv >= 0) hipLaunchKernelGGL(mn_cc_borders2, tiles2, dim3(128), 0, st, P, lbits, c->parent, kh, kv, dv, dbg);
-    if (kh >= 0) kmask &= ~(1u << kh);
-    if (kv >= 0) kmask &= ~(1u << kv);
-    const dim3 gf(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256));
-    hipLaunchKernelGGL(mn_cc_flat_roots, gf, b, 0, st, P, c->parent, c->osize, c->lp_acc, clsmin, clsmax, c->matched);
-    // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
-    fork_by_hook = fork_ext && kmask;
-    if (kmask) {
-      const dim3 gl(8 * ((grid_for(lanes, 256) + 7) / 8));
-      if (fork_by_hook)
-        hipExtLaunchKernelGGL(mn_cc_link, gl, b, 0, st, nullptr, c->ev_fork, 0, P, lbits, c->parent, kh, kv, dv, kmask, dbg);
-      else
-        hipLaunchKernelGGL(mn_cc_link, gl, b, 0, st, P, lbits, c->parent, kh, kv, dv, kmask, dbg);
-    }
-  } else {
+  const bool fork_ext = fork_before_sums && c->ext_events && !c->replay.capturing;
+  bool fork_by_hook = false;
   hipLaunchKernelGGL(mn_cc_tiles, tiles, dim3(MN_CC_TILE_ROWS * 64), 0, st, P, lbits, c->parent, kh, kv, dv,
                      c->osize, c->lp_acc, clsmin, clsmax, c->matched);   // `matched` is free in this mode
   if (kh >= 0 || kv >= 0) {
@@ -921,27 +850,12 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     if (kh >= 0) kmask &= ~(1u << kh);
     if (kv >= 0) kmask &= ~(1u << kv);
   }
-  // debug_flags bit 12: fork behind the border stage -- flatten and hook join the side stream
-  if (fork_before_sums && (c->debug_flags & 4096) && !c->replay.capturing && !cores && !early_fork) {
-    MN_HIP(hipEventRecord(c->ev_fork, st));
-    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    st = c->side;
-    mid_fork = true;
-  }
   hipLaunchKernelGGL(mn_cc_flatten, dim3(grid_for((size_t)(N >> 2) > 0 ? (size_t)(N >> 2) : 1, 256)), b, 0, st, N, c->parent);
-  // debug_flags bit 13: fork behind the flatten stage -- the hook joins the side stream
-  if (fork_before_sums && (c->debug_flags & 8192) && !c->replay.capturing && !cores && !early_fork && !mid_fork) {
-    MN_HIP(hipEventRecord(c->ev_fork, st));
-    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    st = c->side;
-    mid_fork = true;
-  }
   // the last kernel on the caller's stream can carry the fork event itself (hipExtLaunchKernel stop event)
-  fork_by_hook = fork_ext && kmask && !mid_fork;
+  fork_by_hook = fork_ext && kmask;
   if (kmask) {
     if (four) launch_cc_px<4>(c, P, st, kmask, true, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
     else launch_cc_px<1>(c, P, st, kmask, true, false, lbits, fork_by_hook ? c->ev_fork : nullptr);
-  }
   }
   if (c->replay.capturing) {
     MN_HIP(hipStreamEndCapture(c->replay.cap, &c->replay.gA));
@@ -960,10 +874,8 @@ static int run_components(mn_context* c, const ImgParams& P, hipStream_t& st, bo
     // write): it moves to the context's side stream, so that the sweeps of the NEXT image (another
     // context, the caller's stream) run beside it instead of behind it.  mn_segment_finish waits
     // for the side stream; nothing of this image is left on the caller's stream after this point.
-    if (!early_fork && !mid_fork) {
-      if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
-      MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    }
+    if (!fork_by_hook) MN_HIP(hipEventRecord(c->ev_fork, st));
+    MN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     st = c->side;
     if (c->replay.capturing) {     // everything from here to the end of the image goes into graph B
       MN_HIP(hipStreamBeginCapture(c->replay.cap, hipStreamCaptureModeThreadLocal));
@@ -1432,7 +1344,7 @@ static int segment_read_back(mn_context* c, const mn_options* opts, int mode, bo
     stats->finisher_steps = c->h_cnt->finisher_steps;
     stats->tied_steps = stats->tied_merges = stats->tied_conflicts = 0;
     stats->tie_order_used = 0;
-    if (mode == MN_MODE_EXACT && c->xw.h_ctl && (!(opts->debug_flags & 256) || c->xw.prerun)) {
+    if (mode == MN_MODE_EXACT && c->xw.h_ctl) {
       stats->tie_order_used = c->tie_used;
       const long long ts = c->xw.h_ctl->tied_steps, tm = c->xw.h_ctl->tied_merges;
       stats->tied_steps = (int)(ts > 0x7FFFFFFF ? 0x7FFFFFFF : ts);
@@ -1522,9 +1434,8 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
         (opts->variant == MN_VARIANT_CSEGMENT ? opts->merge_logprob_bias >= 0.0f
                                               : opts->merge_logprob_bias == 0.0f)))
     mode = MN_MODE_ROUNDS;
-  // the sequential order at any size: the exact engine (debug_flags bit 8 keeps the small-list finisher
-  // with its O(R) arg-max per step, for comparison)
-  const bool xengine = mode == MN_MODE_EXACT && (!(opts->debug_flags & 256) || c->xw.prerun);
+  // the sequential order at any size: the exact engine
+  const bool xengine = mode == MN_MODE_EXACT;
   c->tie_ref = xengine ? opts->tie_order : MN_TIES_LOWEST_ID;
   c->tie_used = 0;
   ObjState S = obj_state(c);
@@ -1648,34 +1559,6 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
     rc = build_list(c, P, st, cap0 < c->cap ? cap0 : c->cap, cur, true, cur, 0, &R);
     if (rc != MN_OK) return rc;
   }
-  // log-odds margin of the contraction arguments in the fixed-point unit of the sums (fill_params)
-  i64 tau_fixed = 1;
-  if (cores_ok) {
-    const double n = (double)N;
-    const double ulp = (double)nextafterf(P.bias, INFINITY) - (double)P.bias;
-    const double tau = fmax(2.0 * n * ulp, 1e-30 * n * n) / (double)P.omf;
-    tau_fixed = (i64)ceil(tau * MN_FIX_ONE) + 1;
-  }
-  // Contraction of order-free clusters of OBJECTS is opt-in (debug_flags bit 9): its argument assumes
-  // every record fresh, while the reference keeps a survivor's records at the priority of their last
-  // re-score (segment.cc:650-707) -- re-scoring the records of a contracted cluster changes the pop order
-  // of the second phase (the crowded seed 6408 lost its equality with the reference that way in round 2).
-  const bool clusters = mode == MN_MODE_ROUNDS && cores_ok && (opts->debug_flags & 512) && !(opts->debug_flags & 8);
-  if (clusters && R > 0) {
-    // order-free clusters of the initial objects (on a sign-separable map: everything)
-    bool merged = false;
-    rc = contract_clusters(c, P, st, cur, R, tau_fixed, &merged);
-    if (rc != MN_OK) return rc;
-    if (merged) {
-      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);
-      if (cap > c->cap) cap = c->cap;
-      int Rn = 0;
-      rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn, true);
-      if (rc != MN_OK) return rc;
-      RecList t = cur; cur = nxt; nxt = t;
-      R = Rn;
-    }
-  }
   if (mode == MN_MODE_ROUNDS || mode == MN_MODE_COMPONENTS) {
     bool first_round = true;
     int productive = subrounds;    // matching sub-rounds of the previous round that paired anything, + 1
@@ -1738,23 +1621,6 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
       RecList t = cur; cur = nxt; nxt = t;
       R = Rn;
       if (selected == 0) break;     // nothing visible any more: the queue is empty
-    }
-  }
-  if (clusters && rounds > 1 && R > 0) {
-    // hand-over: all records fresh (as the sequential phase always started), then the clusters the
-    // rounds have made order-free go in one step instead of one finisher step per fragment
-    hipLaunchKernelGGL(mn_rec_refresh, dim3(grid_for(R, 256)), dim3(256), 0, st, P, S, cur, R);
-    bool merged = false;
-    rc = contract_clusters(c, P, st, cur, R, tau_fixed, &merged);
-    if (rc != MN_OK) return rc;
-    if (merged) {
-      size_t cap = next_pow2((size_t)R + (size_t)R / 2 + 1024);
-      if (cap > c->cap) cap = c->cap;
-      int Rn = 0;
-      rc = build_list(c, P, st, cap, nxt, false, cur, R, &Rn, true);
-      if (rc != MN_OK) return rc;
-      RecList t = cur; cur = nxt; nxt = t;
-      R = Rn;
     }
   }
   const bool want_cert = opts->compute_logprob != 0;
@@ -2177,7 +2043,7 @@ extern "C" int mn_sweep_device(mn_context* c, const float* d_class_pred, int cla
   c->debug_flags = opts->debug_flags | 2;          // (no events)
   c->ext_events = 0;
   c->cc_clean = 0;
-  const bool four = (N & 3) == 0;               // (4 pixels per lane: also with W % 4 != 0, see run_components)
+  const bool four = (N & 3) == 0 && P.W >= 4;   // (4 pixels per lane: also with W % 4 != 0, see run_components)
   const bool fused_cls = four;
   const size_t sign_blocks = grid_for((size_t)(four ? N / 4 : N), MN_CC_SIGN_THREADS);
   const size_t sign_waves = sign_blocks * (MN_CC_SIGN_THREADS / 64);
@@ -2225,7 +2091,7 @@ extern "C" int mn_sweep_time_device(mn_context* c, const float* const* d_class_p
   c->ext_events = 0;
   c->cc_clean = 0;
   const int N = W * H;
-  const bool four = (N & 3) == 0;
+  const bool four = (N & 3) == 0 && W >= 4;
   MN_HIP(hipMemsetAsync(c->scalars, 0, MN_NSCALARS * sizeof(int), st));
   for (int phase = 0; phase < 2; phase++) {          // a tenth of the launches untimed first
     const int n = phase == 0 ? (reps + 9) / 10 : reps;

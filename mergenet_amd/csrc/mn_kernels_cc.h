@@ -14,11 +14,12 @@
 // -- in whatever order -- and only then turns to the records between components.  The state at
 // that moment (objects = components, one fully summed record per adjacent pair) is what this
 // file builds directly.  The O sameness planes are read from HBM exactly ONCE:
-//   mn_cc_sign     THE sweep over the sameness planes (4 B per value, the roofline-judged pass of
-//                  this mode): per pixel a bit mask of its positive out-edges (4 B/pixel), the
-//                  margin test of (a)/(b), the log sums of the certificate, and a compact list of
-//                  the negative edges (edge id, log-odds) -- the only edges whose value is needed
-//                  again; everything after this kernel works on the 4 B/pixel mask;
+//   mn_cc_sign     THE sweep over the class and sameness planes (4 B per value, the roofline-judged pass
+//                  of this mode): per pixel a bit mask of its positive out-edges and one of its negative
+//                  out-edges (4 + 4 B/pixel), the margin test of (a)/(b), the log sums of the certificate,
+//                  per lane and class the fixed-point log of the product of its four pixels' class values;
+//                  everything after this kernel works on the masks (mn_cc_cross reads the values of the
+//                  negative edges again: 1.2 M of 21 M at 1024x2048);
 //   mn_cc_tiles    16 x 64-pixel tiles labelled in LDS over the two unit offsets (mask bits); flat
 //                  within the tile; accumulators of the tile roots cleared;
 //   mn_cc_borders  unit-offset edges across tile borders; mn_cc_flatten  parent[p] = root, once;
@@ -27,8 +28,8 @@
 //   mn_cc_class_sums  the class pass: arg-max class of every pixel, component sizes, class
 //                  log-prob sums and class range (block table in LDS, 64-bit fixed-point atomics);
 //                  also leaves parent[] flat;
-//   mn_cc_cross    the negative-edge list -> records between components (block table in LDS,
-//                  then the global table); a negative edge inside a component fails (a);
+//   mn_cc_cross    the mask of negative out-edges -> records between components (block scan, LDS queue,
+//                  block table in LDS, then the global table); a negative edge inside a component fails (a);
 //   mn_cc_finish   fixed-point sums -> float object state, condition (c), list of component roots.
 // The second phase (records between components, where the bias lets a 1.6 M-pixel background
 // swallow small instances) is then run by the sequential finisher in the reference's order,
@@ -64,15 +65,17 @@ __device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) 
   return make_int4(t.x, t.y, t.z, t.w);
 }
 
-// ---- the sweep over the sameness planes ---------------------------------------------------------
-// One lane takes PX consecutive pixels of one row (PX = 4 with 16-byte loads when W % 4 == 0, else
-// 1).  For every in-bounds (pixel, offset) pair the value decides: >= sep_hi the edge is positive
-// (bit k of the pixel's mask), <= sep_lo it is negative (the edge goes to the compact list), in
-// between the map is not separable (margins: fill_params).  The negative edges -- a few per cent,
-// along the instance boundaries -- are the only ones whose value is needed again (log-odds of the
-// records between components), so they leave as 8-byte entries  (offset << 26 | pixel) << 32 |
-// float bits of the log-odds  and nothing downstream reads the planes again.
-// Algorithmic HBM bytes: 4 * O per pixel read (83.9 MB at 1024x2048, O = 10).
+// ---- the sweep over the class and sameness planes -------------------------------------------------
+// One lane takes PX consecutive pixels (PX = 4 with 16-byte loads whenever N % 4 == 0 and W >= 4 -- with
+// W % 4 != 0 one lane per row runs over the row's end: `straddle` --, else 1).  For every in-bounds
+// (pixel, offset) pair the value decides: >= sep_hi the edge is positive (bit k of the pixel's positive
+// mask), <= sep_lo it is negative (bit k of its negative mask), in between the map is not separable
+// (margins: fill_params).  The negative edges -- a few per cent, along the instance boundaries -- are the
+// only ones whose value is needed again (log-odds of the records between components): mn_cc_cross, on the
+// side stream, enumerates the negative mask and reads those values again.  (Round 2 queued them in LDS and
+// wrote a list from inside the sweep: two barriers at the end of every block and 168 MB of list regions
+// per context; without it the sweep has neither LDS nor barrier: 37.7 instead of 43.8 us.)
+// Algorithmic HBM bytes: 4 * (C + O) per pixel read (159.4 MB at 1024x2048, C = 9, O = 10).
 //
 // The pass is VALU-bound as soon as a value costs more than ~15 instructions (a wave64
 // instruction takes 4 cycles; PMC: the first version ran 54 per value, 70 % VALU-busy), so:
@@ -80,15 +83,8 @@ __device__ __forceinline__ int4 mn_ld_int4_unaligned(const int* __restrict__ p) 
 //    waves of a row) skips the per-value bounds tests: a row outside the image just loads 1.0;
 //  * the certificate only needs  sum log v (inside) + sum log(1-v) (between) = sum log max(v, 1-v)
 //    on a separable map, taken as the log of a PRODUCT per lane (factors in [0.5, 1], folded
-//    every 80 factors): one max and one multiply per value instead of a log;
-//  * negative edges are counted by popcount, queued in LDS as 2-byte items (pixel in block,
-//    offset) and then worked off by ALL lanes of the block, one item each (load the value again --
-//    an L2 / Infinity Cache hit --, logf, log(1-v), write): dense work and coalesced writes
-//    instead of 40 divergent iterations in the few lanes that sit on a boundary.
-// Every block owns a fixed region of the list, large enough for all its edges (256 * PX * O
-// entries; 288 GB of HBM make that affordable: 168 MB at 1024x2048), and leaves its count in
-// neg_count[block]: no atomic, no reservation to wait for.  PLAIN: no clip and no
-// same_different_bias (the production setting), decided at compile time.
+//    every 80 factors): one max and one multiply per value instead of a log.
+// PLAIN: no clip and no same_different_bias (the production setting), decided at compile time.
 #define MN_CC_SIGN_THREADS 256
 #define MN_CC_SIGN_G 5           /* offsets whose loads are in flight together */
 #define MN_CC_EDGE_PIXBITS 26    /* components mode serves N <= 2^26 */
@@ -557,309 +553,6 @@ __global__ __launch_bounds__(256) void mn_cc_hook(ImgParams P, const unsigned* _
         mn_cc_wave_union(parent, want, a, bb);
       }
     }
-  }
-}
-
-// ---- labelling by ROW RUNS in wide tiles (round 3) ------------------------------------------------------
-// The tile pipeline above spends 59 us per 1024x2048 image in four dependent launches (LDS union-find
-// per 16 x 64 tile over single pixels, border unions, a flatten, the sweep over the other offsets) and
-// moves 11x the bytes of the masks it reads.  Inside an instance nearly every horizontal unit edge is
-// positive, so a row falls into a few long RUNS; with runs as the union-find elements almost no pixel
-// ever enters it:
-//   mn_cc_tiles2      a block owns 16 rows x 256 columns: a wave takes a row (4 pixels per lane), run
-//                     starts from one ballot and one cross-lane read, vertical unit edges inside the tile
-//                     united in LDS -- a request that repeats the previous pixel's (same two runs) is
-//                     dropped, so two runs cost one union however long they are; parent[p] = tile root;
-//   mn_cc_borders2    the unit edges across tile borders (272 per tile, repeats dropped the same way);
-//   mn_cc_flat_roots  parent[p] = root, root candidates flagged, the roots' accumulators cleared;
-//   mn_cc_link        the other offsets: a lane compares the parents of its 4 pixels with those of the 4
-//                     neighbours (one unaligned 16-byte read per offset) -- equal for nearly every edge
-//                     now that the 4-connected regions are flat -- and again drops repeats.
-// (Measured on the way: runs across the whole image without the LDS stage -- the vertical unions then
-//  build chains as deep as the image is high, link sweep 100 us; tiles2 + one link sweep over ALL offsets
-//  without the flatten in between -- parents of different tiles never compare equal, 66 us.)
-#define MN_T2_ROWS 16
-#define MN_T2_COLS 256
-struct __attribute__((packed, aligned(4))) mn_uint4u { unsigned x, y, z, w; };
-
-__device__ __forceinline__ int mn_dpp_prev_lane(int v) {          // lane l gets lane l-1's value, lane 0 gets 0
-#ifdef MN_LBL_NODPP
-  return 0;
-#endif
-  return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);   // wave_shr:1
-}
-
-// lock-free union of the sets of x and y: the larger root is hooked under the smaller
-__device__ __forceinline__ void mn_cc_unite(int* __restrict__ parent, int x, int y) {
-  int a = mn_cc_find(parent, x), b = mn_cc_find(parent, y);
-  while (a != b) {
-    if (a < b) { const int t = a; a = b; b = t; }
-    const int old = atomicMin(&parent[a], b);
-    if (old == a) break;
-    a = mn_cc_find(parent, old);
-    b = mn_cc_find(parent, b);
-  }
-}
-
-// The same with RANDOMISED linking for the stages that work on global memory: hooking "larger id under
-// smaller" builds trees as deep as the tile grid is wide and high (every tile root is asked for by its
-// left AND its upper neighbour; the loser of the race climbs the winner's chain and tries again one
-// level up), a hash of the id as linking priority keeps the expected depth logarithmic whatever the
-// order of the unions.  Nothing downstream needs the root to be the smallest pixel of its component.
-__device__ __forceinline__ unsigned mn_cc_prio(int x) {
-  unsigned h = (unsigned)x * 0x9E3779B1u;
-  h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
-  return h;
-}
-__device__ __forceinline__ void mn_cc_unite_rand(int* __restrict__ parent, int x, int y) {
-#ifdef MN_LBL_NOUNITE
-  return;
-#endif
-  int a = mn_cc_find(parent, x), b = mn_cc_find(parent, y);
-  while (a != b) {
-    const unsigned ha = mn_cc_prio(a), hb = mn_cc_prio(b);
-    if (ha < hb || (ha == hb && a < b)) { const int t = a; a = b; b = t; }   // a: the larger priority goes under b
-    const int old = atomicCAS(&parent[a], a, b);
-    if (old == a) break;
-    a = mn_cc_find(parent, old);
-    b = mn_cc_find(parent, b);
-  }
-}
-
-__global__ __launch_bounds__(MN_T2_ROWS * 64) void mn_cc_tiles2(ImgParams P, const unsigned* __restrict__ bits,
-                                                               int* __restrict__ parent, int kh, int kv, int dv) {
-  __shared__ int lab[MN_T2_ROWS * MN_T2_COLS];
-  const int t = threadIdx.x, lane = t & 63, i = t >> 6;             // wave i = row i of the tile
-  const int r = (int)blockIdx.y * MN_T2_ROWS + i, c0 = (int)blockIdx.x * MN_T2_COLS + lane * 4;
-  const int nv = (r < P.H) ? max(0, min(4, P.W - c0)) : 0;
-  const int p0 = r * P.W + c0;
-  unsigned b[4] = {0u, 0u, 0u, 0u};
-  if (nv == 4) {
-    const mn_uint4u v = *reinterpret_cast<const mn_uint4u*>(bits + p0);
-    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-  } else {
-    for (int j = 0; j < nv; j++) b[j] = bits[p0 + j];
-  }
-  // link j: pixel j -> pixel j + 1 of the row (a set bit implies an in-bounds neighbour); the last
-  // lane's link leaves the tile (mn_cc_link takes it)
-  const bool l0 = kh >= 0 && ((b[0] >> kh) & 1u), l1 = kh >= 0 && ((b[1] >> kh) & 1u);
-  const bool l2 = kh >= 0 && ((b[2] >> kh) & 1u), l3 = kh >= 0 && ((b[3] >> kh) & 1u) && lane < 63;
-  const bool enter = mn_dpp_prev_lane(l3 ? 1 : 0) != 0;             // from the previous lane's last pixel
-  const int tail = !l2 ? 3 : (!l1 ? 2 : (!l0 ? 1 : 0));             // first pixel of the run that leaves the lane
-  const bool transparent = enter && l0 && l1 && l2;                 // one run passes through
-  const u64 nt = __ballot(!transparent);
-  const u64 below = nt & ((1ull << lane) - 1ull);
-  const int src = below ? (63 - __clzll((long long)below)) : 0;     // nearest lane below where the entering run starts
-  const int base = i * MN_T2_COLS + lane * 4;                       // local id of the lane's first pixel
-  const int sin = __shfl(base + tail, src);
-  int s[4];
-  s[0] = enter ? sin : base;
-  s[1] = l0 ? s[0] : base + 1;
-  s[2] = l1 ? s[1] : base + 2;
-  s[3] = l2 ? s[2] : base + 3;
-  *reinterpret_cast<int4*>(&lab[base]) = make_int4(s[0], s[1], s[2], s[3]);
-  __syncthreads();
-  // vertical unit edges that stay inside the tile
-  const int ni = i + dv;
-  if (kv >= 0 && ni >= 0 && ni < MN_T2_ROWS) {
-    const int4 nb = *reinterpret_cast<const int4*>(&lab[ni * MN_T2_COLS + lane * 4]);
-    const int q[4] = {nb.x, nb.y, nb.z, nb.w};
-    bool req[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> kv) & 1u) != 0u;
-    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
-    const int ps = mn_dpp_prev_lane(s[3]), pq = mn_dpp_prev_lane(q[3]);
-    bool go[4];
-    go[0] = req[0] && !(preq && ps == s[0] && pq == q[0]);
-#pragma unroll
-    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && s[j - 1] == s[j] && q[j - 1] == q[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (go[j]) mn_cc_unite(lab, s[j], q[j]);
-  }
-  __syncthreads();
-  if (nv == 0) return;
-  int o[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int x = (j > 0 && s[j] == s[j - 1]) ? -1 : s[j];
-    if (x >= 0) { while (lab[x] != x) x = lab[x]; }
-    o[j] = x >= 0 ? ((int)blockIdx.y * MN_T2_ROWS + (x >> 8)) * P.W + (int)blockIdx.x * MN_T2_COLS + (x & (MN_T2_COLS - 1))
-                  : o[j > 0 ? j - 1 : 0];
-  }
-  if (nv == 4) {
-    mn_int4u w; w.x = o[0]; w.y = o[1]; w.z = o[2]; w.w = o[3];
-    *reinterpret_cast<mn_int4u*>(parent + p0) = w;
-  } else {
-    for (int j = 0; j < nv; j++) parent[p0 + j] = o[j];
-  }
-}
-
-// unit edges across the borders of the 16 x 256 tiles: wave 0 takes the 256 vertical edges that leave the
-// tile (4 per lane), wave 1 the 16 horizontal ones across its right border; repeats of the previous
-// pixel's request are dropped, so a border segment inside one pair of components costs one union
-__global__ __launch_bounds__(128) void mn_cc_borders2(ImgParams P, const unsigned* __restrict__ bits,
-                                                      int* __restrict__ parent, int kh, int kv, int dv, int* dbg) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r0 = (int)blockIdx.y * MN_T2_ROWS, cb = (int)blockIdx.x * MN_T2_COLS;
-  if (wave == 0) {
-    if (kv < 0) return;
-    const int r = dv > 0 ? min(r0 + MN_T2_ROWS - 1, P.H - 1) : r0;
-    // (a tile cut by the image's lower edge has no lower border; its rows' bits are clear there anyway)
-    if (dv > 0 && r0 + MN_T2_ROWS - 1 >= P.H) return;
-    if (r + dv < 0 || r + dv >= P.H) return;
-    const int c0 = cb + lane * 4;
-    const int nv = max(0, min(4, P.W - c0));
-    const int p0 = r * P.W + c0, q0 = p0 + dv * P.W;
-    unsigned b[4] = {0u, 0u, 0u, 0u};
-    int own[4] = {-1, -2, -3, -4}, rq[4] = {-1, -2, -3, -4};
-    if (nv == 4) {
-      const mn_uint4u t = *reinterpret_cast<const mn_uint4u*>(bits + p0);
-      b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
-      const int4 o = mn_ld_int4_unaligned(parent + p0), n = mn_ld_int4_unaligned(parent + q0);
-      own[0] = o.x; own[1] = o.y; own[2] = o.z; own[3] = o.w;
-      rq[0] = n.x; rq[1] = n.y; rq[2] = n.z; rq[3] = n.w;
-    } else {
-      for (int j = 0; j < nv; j++) { b[j] = bits[p0 + j]; own[j] = parent[p0 + j]; rq[j] = parent[q0 + j]; }
-    }
-    bool req[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) req[j] = ((b[j] >> kv) & 1u) && rq[j] != own[j];
-    const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
-    const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[3]);
-    bool go[4];
-    go[0] = req[0] && !(preq && pown == own[0] && prq == rq[0]);
-#pragma unroll
-    for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[j - 1] == rq[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (go[j]) { mn_cc_unite_rand(parent, own[j], rq[j]); if (dbg) atomicAdd(dbg, 1); }
-  } else {
-    if (kh < 0) return;
-    const int r = r0 + lane, c = cb + MN_T2_COLS - 1;
-    const bool in = lane < MN_T2_ROWS && r < P.H && c + 1 < P.W;
-    const int p = in ? r * P.W + c : 0;
-    int own = -1, rq = -2;
-    bool req = false;
-    if (in && ((bits[p] >> kh) & 1u)) { own = parent[p]; rq = parent[p + 1]; req = own != rq; }
-    const bool preq = mn_dpp_prev_lane(req ? 1 : 0) != 0;
-    const int pown = mn_dpp_prev_lane(own), prq = mn_dpp_prev_lane(rq);
-    if (req && !(preq && pown == own && prq == rq)) { mn_cc_unite_rand(parent, own, rq); if (dbg) atomicAdd(dbg + 1, 1); }
-  }
-}
-
-__global__ __launch_bounds__(256) void mn_cc_link(ImgParams P, const unsigned* __restrict__ bits,
-                                                  int* __restrict__ parent, int kh, int kv, int dv, unsigned kmask, int* dbg) {
-  const int lpr = (P.W + 3) >> 2, total = lpr * P.H;
-  const int tile = mn_xcd_tile((total + 255) >> 8, P.banded);
-  const int i = tile < 0 ? total : tile * 256 + (int)threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool live = i < total;
-  const int r = live ? i / lpr : 0, c0 = live ? ((i - r * lpr) << 2) : 0;
-  const int nv = live ? min(4, P.W - c0) : 0;
-  const int p0 = r * P.W + c0;
-  unsigned b[4] = {0u, 0u, 0u, 0u};
-  int own[4] = {-1, -2, -3, -4};
-  if (nv == 4) {
-    const mn_uint4u t = *reinterpret_cast<const mn_uint4u*>(bits + p0);
-    b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
-    const int4 o = mn_ld_int4_unaligned(parent + p0);
-    own[0] = o.x; own[1] = o.y; own[2] = o.z; own[3] = o.w;
-  } else {
-    for (int j = 0; j < nv; j++) { b[j] = bits[p0 + j]; own[j] = parent[p0 + j]; }
-  }
-  // the unit offsets (if asked for at all) were taken by mn_cc_tiles2 except across tile borders
-  if (kh >= 0 && ((kmask >> kh) & 1u)) {
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (((c0 + j) & (MN_T2_COLS - 1)) != MN_T2_COLS - 1) b[j] &= ~(1u << kh);
-  }
-  if (kv >= 0 && ((kmask >> kv) & 1u)) {
-    const bool border_row = dv > 0 ? ((r & (MN_T2_ROWS - 1)) == MN_T2_ROWS - 1) : ((r & (MN_T2_ROWS - 1)) == 0);
-    if (!border_row) { b[0] &= ~(1u << kv); b[1] &= ~(1u << kv); b[2] &= ~(1u << kv); b[3] &= ~(1u << kv); }
-  }
-  const unsigned any = (b[0] | b[1] | b[2] | b[3]) & kmask;
-  constexpr int G = 4;                        // offsets whose loads are in flight together
-  for (int k0 = 0; k0 < P.O; k0 += G) {
-    if (__ballot((any >> k0) & ((1u << G) - 1u)) == 0) continue;    // uniform
-    int rq[G][4];
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int k = k0 + g;
-#pragma unroll
-      for (int j = 0; j < 4; j++) rq[g][j] = own[j];
-      if (k < P.O && ((any >> k) & 1u)) {
-        const long long q0 = (long long)(r + P.di[k]) * P.W + c0 + P.dj[k];
-        if (q0 >= 0 && q0 + 3 < P.N) {
-          const int4 t = mn_ld_int4_unaligned(parent + q0);
-          rq[g][0] = t.x; rq[g][1] = t.y; rq[g][2] = t.z; rq[g][3] = t.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (((b[j] >> k) & 1u) && q0 + j >= 0 && q0 + j < P.N) rq[g][j] = parent[q0 + j];
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int k = k0 + g;
-      if (k >= P.O) break;                    // uniform
-      if (!((kmask >> k) & 1u)) continue;
-      bool req[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) req[j] = ((b[j] >> k) & 1u) && rq[g][j] != own[j];
-      if (__ballot(req[0] || req[1] || req[2] || req[3]) == 0) continue;      // uniform: nearly always
-      // a request equal to the previous pixel's (same two sets asked for) is dropped
-      const bool preq = mn_dpp_prev_lane(req[3] ? 1 : 0) != 0;
-      const int pown = mn_dpp_prev_lane(own[3]), prq = mn_dpp_prev_lane(rq[g][3]);
-      bool go[4];
-      go[0] = req[0] && !(preq && lane != 0 && pown == own[0] && prq == rq[g][0]);
-#pragma unroll
-      for (int j = 1; j < 4; j++) go[j] = req[j] && !(req[j - 1] && own[j - 1] == own[j] && rq[g][j - 1] == rq[g][j]);
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (go[j]) { mn_cc_unite_rand(parent, own[j], rq[g][j]); if (dbg) atomicAdd(dbg + 2, 1); }
-    }
-  }
-}
-
-// parent[p] = root for every pixel; the roots -- the component roots: no union follows -- are flagged
-// and their accumulators cleared (class sums, class range, size)
-__global__ __launch_bounds__(256) void mn_cc_flat_roots(ImgParams P, int* __restrict__ parent, int* __restrict__ osize,
-                                                        i64* __restrict__ lp_acc, int* __restrict__ clsmin,
-                                                        int* __restrict__ clsmax, unsigned char* __restrict__ cand) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int N = P.N, n4 = N >> 2;
-  auto root_of = [&](int x) { int y = parent[x]; while (y != x) { x = y; y = parent[x]; } return x; };
-  auto clear_root = [&](int p) {
-    osize[p] = 0;
-    for (int c = 0; c < P.C; c++) lp_acc[(size_t)c * N + p] = 0;
-    clsmin[p] = 255;
-    clsmax[p] = 0;
-  };
-  if (i < n4) {
-    const int p0 = 4 * i;
-    const int4 r = *reinterpret_cast<const int4*>(parent + p0);
-    int4 o;
-    o.x = (r.x == p0) ? p0 : root_of(r.x);
-    o.y = (r.y == r.x) ? o.x : ((r.y == p0 + 1) ? p0 + 1 : root_of(r.y));
-    o.z = (r.z == r.y) ? o.y : ((r.z == p0 + 2) ? p0 + 2 : root_of(r.z));
-    o.w = (r.w == r.z) ? o.z : ((r.w == p0 + 3) ? p0 + 3 : root_of(r.w));
-    if (o.x != r.x || o.y != r.y || o.z != r.z || o.w != r.w) *reinterpret_cast<int4*>(parent + p0) = o;
-    uchar4 cd;
-    cd.x = o.x == p0; cd.y = o.y == p0 + 1; cd.z = o.z == p0 + 2; cd.w = o.w == p0 + 3;
-    *reinterpret_cast<uchar4*>(cand + p0) = cd;
-    if (cd.x) clear_root(p0);
-    if (cd.y) clear_root(p0 + 1);
-    if (cd.z) clear_root(p0 + 2);
-    if (cd.w) clear_root(p0 + 3);
-  }
-  if (i < N - (n4 << 2)) {
-    const int p = (n4 << 2) + i;
-    const int x = root_of(p);
-    parent[p] = x;
-    cand[p] = x == p;
-    if (x == p) clear_root(p);
   }
 }
 

@@ -111,12 +111,13 @@ struct XState {
 // differentness_logprob = log(1.0 - same_prob): a double log rounded to float (segment.cc:34)
 __device__ __forceinline__ float mn_ref_log1m(float v) { return (float)log(1.0 - (double)v); }
 
-// same_different_bias applied on load (segment.cc:183-195: float logf, double log, expf, double division)
+// same_different_bias applied on load (segment.cc:183-195: float logf, double log, expf, double division;
+// glibc's logf and expf restated bit for bit: mn_ref_logf.h)
 __device__ __forceinline__ float mn_ref_same_value(const ImgParams& P, float v) {
   if (P.clip) v = mn_clip(v);
   if (P.sdb != 0.0f) {
     const float logit = (float)(((double)mn_ref_logf(v) - log(1.0 - (double)v)) + (double)P.sdb);
-    v = (float)(1.0 / (1.0 + (double)expf(-logit)));
+    v = (float)(1.0 / (1.0 + (double)mn_ref_expf(-logit)));
   }
   return v;
 }

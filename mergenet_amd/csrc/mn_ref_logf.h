@@ -48,3 +48,43 @@ MN_REF_HD float mn_ref_logf(float x) {
   y = __builtin_fma(r2, -0x1.00ea348b88334p-2, y);
   return (float)__builtin_fma(r2, y, t);
 }
+
+// glibc's expf, bit for bit (the reference's same_different_bias path: `exp(-logit)` on a float is expf,
+// utils/csegment/segment.cc:183-195).  glibc 2.35's published algorithm (sysdeps/ieee754/flt-32/e_expf.c, from
+// ARM's optimized routines): in double precision, x * 32 / ln 2 = k + r with k rounded to nearest (adding and
+// subtracting 1.5 * 2^52), exp x = 2^(k/32) * (C0 r^3 + C1 r^2 + C2 r + 1), 2^(i/32) from a 32-entry table whose
+// exponent field takes k's upper bits.  Operation order of the FMA variant x86-64 dispatches to.  |x| < 88 only
+// (the logit of a clipped probability plus a bias: |x| <= 16 + |bias|); overflow, underflow and NaN are not
+// handled.  Equal to the C library's expf on all 6.1e8 floats with 2^-30 <= |x| < 80 when it was written;
+// tests/test_ref_logf.py compares the host build with the C library's expf on a sample.
+MN_REF_HD float mn_ref_expf(float x) {
+  const unsigned long long T[32] = {
+      0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+      0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+      0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+      0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+      0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+      0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+      0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+      0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+  const double shift = 0x1.8p+52;
+  const double xd = (double)x;
+  const double z = (0x1.71547652b82fep+0 * 32.0) * xd;
+  double kd = z + shift;
+  unsigned long long ki;
+  __builtin_memcpy(&ki, &kd, 8);
+  kd -= shift;
+  const double r = __builtin_fma(0x1.71547652b82fep+0 * 32.0, xd, -kd);   // (the FMA variant fuses z - kd with z's product)
+  unsigned long long t = T[ki & 31ull];
+  t += ki << (52 - 5);
+  double s;
+  __builtin_memcpy(&s, &t, 8);
+  const double c0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, c1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0,
+               c2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+  const double zz = __builtin_fma(c0, r, c1);
+  const double r2 = r * r;
+  double y = __builtin_fma(c2, r, 1.0);
+  y = __builtin_fma(zz, r2, y);
+  y = y * s;
+  return (float)y;
+}

@@ -156,11 +156,18 @@ class MaskExchange:
                      for _ in range(depth)]
         self.work = [None] * depth
         self.filled = [0] * depth          # submits packed into the slot's send buffer and not yet sent
-        self.kept = [[None] * self.batch for _ in range(depth)]   # inputs of a batch, for the int16 fallback
+        # int16 copy of every submit of a batch, packed AT SUBMIT TIME (the fallback of an overflowing run-length
+        # wire must not depend on the caller keeping its mask alive or unchanged: a pipelined loop reuses its
+        # output buffers long before the results of a batch are read)
+        self.words16 = self.n + 1 + MAX_INSTANCES + 4
+        self.stage = ([torch.empty(self.batch * self.words16, dtype=torch.int16, device=device) for _ in range(depth)]
+                      if fmt == "runs" else None)
         self.fallback = {}                 # (slot, pos) -> gathered int16 wires of an overflowed submit
+        self.serial = [0] * depth          # number of the batch a slot holds (tags the fallback exchange)
         self.count = 0
         self._host_wait_ms = 0.0
         self._stall_events = []            # (before, after) event pairs around work.wait() on the compute stream
+        self._stall_done_ms = 0.0          # ... finished pairs, summed
         self.bytes_per_rank = self.words * (4 if fmt == "runs" else 2)
 
     def _pack(self, mask, class_table, num_instances, wire, total_logprob):
@@ -195,8 +202,16 @@ class MaskExchange:
         self._pack(mask, class_table, num_instances,
                    self.send[slot][pos * self.words:(pos + 1) * self.words], total_logprob)
         if self.fmt == "runs":
-            self.kept[slot][pos] = (mask, class_table, num_instances, total_logprob)
+            saved = self.fmt
+            self.fmt = "int16"
+            try:
+                self._pack(mask, class_table, num_instances,
+                           self.stage[slot][pos * self.words16:(pos + 1) * self.words16], total_logprob)
+            finally:
+                self.fmt = saved
             self.fallback.pop((slot, pos), None)
+        if pos == 0:
+            self.serial[slot] = self.count // self.batch
         self.filled[slot] = pos + 1
         if pos == self.batch - 1:
             self._launch(slot)
@@ -235,6 +250,11 @@ class MaskExchange:
             if cuda:
                 b.record()
                 self._stall_events.append((a, b))
+                # pairs that have completed are folded into the running sum (a long loop would otherwise keep
+                # two events per collective for ever and re-read all of them on every wait_ms)
+                while len(self._stall_events) > 8 and self._stall_events[0][1].query():
+                    a0, b0 = self._stall_events.pop(0)
+                    self._stall_done_ms += a0.elapsed_time(b0)
             self._host_wait_ms += (time.perf_counter() - t) * 1e3
             self.work[slot] = None
 
@@ -243,40 +263,46 @@ class MaskExchange:
         """Milliseconds the loop was held up by collectives so far: host time inside wait() plus, on the
         GPU, the stall of the compute stream behind each collective (event pairs; reading it synchronises
         with the last of them)."""
-        stall = 0.0
         for a, b in self._stall_events:
             b.synchronize()
-            stall += a.elapsed_time(b)
-        return self._host_wait_ms + stall
+            self._stall_done_ms += a.elapsed_time(b)
+        self._stall_events = []
+        return self._host_wait_ms + self._stall_done_ms
 
     @wait_ms.setter
     def wait_ms(self, v: float) -> None:
         self._host_wait_ms = float(v)
         self._stall_events = []
+        self._stall_done_ms = 0.0
 
     def _int16_fallback(self, slot: int, pos: int):
         """A rank's mask had more label changes than the run-length wire holds (header -1, seen by every
-        rank in the gathered batch): that submit is exchanged again as an int16 map, by every rank at the
-        same point (all of them read the same headers), from the inputs kept with the batch."""
+        rank in the gathered batch): that submit is exchanged again as an int16 map, from the copy packed at
+        submit time.  This is a COLLECTIVE issued from ``result`` / ``logprobs``: as with any collective, every
+        rank must ask for the results of its handles at the same points of its loop and in the same order.
+        The exchange carries the handle's number; ranks that disagree raise instead of delivering another
+        submit's mask."""
         key = (slot, pos)
         if key in self.fallback:
             return self.fallback[key]
         torch = self.torch
-        mask, table, k, lp = self.kept[slot][pos]
-        words = self.n + 1 + MAX_INSTANCES + 4
+        words = self.words16 + 4
         send = torch.empty(words, dtype=torch.int16, device=self.send[slot].device)
-        saved = self.fmt
-        self.fmt = "int16"
-        try:
-            self._pack(mask, table, k, send, lp)
-        finally:
-            self.fmt = saved
+        send[: self.words16] = self.stage[slot][pos * self.words16:(pos + 1) * self.words16]
+        tag = self.serial[slot] * self.batch + pos
+        send[self.words16:] = torch.tensor([tag], dtype=torch.int64).view(torch.int16).to(send.device)
         recv = torch.empty(self.world * words, dtype=torch.int16, device=send.device)
         if self.world == 1:
             recv.copy_(send)
         else:
             self.dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
-        self.fallback[key] = recv.view(self.world, words)
+        got = recv.view(self.world, words)
+        tags = got[:, self.words16:].reshape(-1).clone().view(torch.int64)
+        if bool((tags != tag).any()):
+            raise RuntimeError("MaskExchange: ranks asked for the results of different submits (%s, here %d): "
+                               "result() / logprobs() must be called for the same handles in the same order on "
+                               "every rank" % (tags.tolist(), tag))
+        self.fallback[key] = got[:, : self.words16]
         return self.fallback[key]
 
     def result(self, slot: int):

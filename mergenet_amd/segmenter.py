@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from collections import namedtuple
 from typing import List, Optional, Sequence, Tuple
 
@@ -31,10 +32,8 @@ MN_VARIANT_PYSEGMENTER = 1
 MN_MODE_AUTO, MN_MODE_EXACT, MN_MODE_ROUNDS, MN_MODE_COMPONENTS = 0, 1, 2, 3
 MN_ERR_NO_BACKGROUND = -10
 MN_ERR_UNPROVEN = -30
-MN_DEBUG_GENERIC_EDGE_PASS, MN_DEBUG_NO_EVENTS, MN_DEBUG_NO_CORES, MN_DEBUG_NO_CLUSTERS = 1, 2, 4, 8
+MN_DEBUG_GENERIC_EDGE_PASS, MN_DEBUG_NO_EVENTS, MN_DEBUG_NO_CORES = 1, 2, 4
 MN_DEBUG_LEAN_EVENTS, MN_DEBUG_REPLAY = 16, 32
-MN_DEBUG_CLUSTERS = 512           # general rounds: contract order-free clusters of objects (opt-in)
-MN_DEBUG_OLD_EXACT = 256          # MN_MODE_EXACT by the small-list finisher instead of the exact engine
 MN_PROVE_ALWAYS, MN_PROVE_BY_MODE, MN_PROVE_NEVER = 1, 0, -1   # mn_options.require_proof
 MN_TIES_DEFAULT, MN_TIES_REFERENCE, MN_TIES_LOWEST_ID = 0, 1, 2   # mn_options.tie_order
 MN_PROOF_NONE, MN_PROOF_CERTIFICATE, MN_PROOF_SEQUENTIAL, MN_PROOF_SEQUENTIAL_TIES = 0, 1, 2, 3   # mn_stats.proof
@@ -315,23 +314,30 @@ class HostContext:
 
 
 _host_contexts = {}
+_host_contexts_lock = threading.Lock()
 
 
 def _cached_host_context(H: int, W: int, C: int, O: int) -> "HostContext":
-    """The HostContext of this shape, created on first use (at most two shapes are kept)."""
-    key = (H, W, C, O)
-    ctx = _host_contexts.get(key)
-    if ctx is None or not ctx.handle:
-        while len(_host_contexts) >= 2:
-            _host_contexts.pop(next(iter(_host_contexts))).close()
-        ctx = _host_contexts[key] = HostContext(H, W, C, O)
-    return ctx
+    """The HostContext of this shape AND this thread, created on first use (at most two shapes per thread are
+    kept).  A context serves one call at a time (mn_context: one thread at a time), so threads do not share
+    one; the cache itself is guarded by a lock, and a context is only evicted by the thread that owns it."""
+    tid = threading.get_ident()
+    key = (tid, H, W, C, O)
+    with _host_contexts_lock:
+        ctx = _host_contexts.get(key)
+        if ctx is None or not ctx.handle:
+            mine = [k for k in _host_contexts if k[0] == tid]
+            while len(mine) >= 2:
+                _host_contexts.pop(mine.pop(0)).close()
+            ctx = _host_contexts[key] = HostContext(H, W, C, O)
+        return ctx
 
 
 def close_cached_contexts() -> None:
-    """Free the contexts ObjectSegmenter keeps between calls."""
-    while _host_contexts:
-        _host_contexts.popitem()[1].close()
+    """Free the contexts ObjectSegmenter keeps between calls (call it when no run_segmentation is in flight)."""
+    with _host_contexts_lock:
+        while _host_contexts:
+            _host_contexts.popitem()[1].close()
 
 
 class ObjectSegmenter:

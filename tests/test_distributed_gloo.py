@@ -218,8 +218,10 @@ def _fallback_worker(rank, world, port, out):
     ok = True
     table = torch.arange(1, 10, dtype=torch.int32)
     # step 0: only rank 1's mask overflows; step 1: nobody's; both in one batch
-    h0 = ex.submit(noisy if rank == 1 else calm, table, 8, -1.5 * (rank + 1))
-    h1 = ex.submit(calm, table, 3, -2.5 * (rank + 1))
+    buf = (noisy if rank == 1 else calm).clone()       # the caller's output buffer ...
+    h0 = ex.submit(buf, table, 8, -1.5 * (rank + 1))
+    buf.fill_(7)                                       # ... reused before the result is read (a pipelined loop
+    h1 = ex.submit(calm, table, 3, -2.5 * (rank + 1))  # does that): the fallback must not read it again
     masks, tabs, counts = ex.result(h0)       # every rank sees rank 1's header -1 and joins the int16 exchange
     ok &= masks.shape == (world, H, W) and masks.dtype == torch.int32
     ok &= bool((masks[1] == noisy).all()) and bool((masks[0] == _test_mask(H, W, 0, 0)).all())
@@ -235,7 +237,8 @@ def _fallback_worker(rank, world, port, out):
 
 def test_mask_exchange_overflowing_mask_falls_back_to_int16_world2_gloo():
     """A mask with more label changes than the run-length wire holds: its header says -1, every rank sees
-    it, and that ONE submit is exchanged again as an int16 map (round 2: result() raised)."""
+    it, and that ONE submit is exchanged again as an int16 map (round 2: result() raised) -- from a copy packed
+    at submit time, so the caller may reuse its mask buffer before reading the result (advisor, round 3)."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()

@@ -32,10 +32,14 @@ def _run(g, mode=seg.MN_MODE_AUTO, **kw):
 @pytest.mark.parametrize("shape", [(256, 512, 9, (40, 10), 0.15, (0.0, 1.0, 0.03)),
                                    (1024, 2048, 9, (40, 10), 0.15, (0.0, 1.0, 0.03)),
                                    (400, 667, 81, (80, 16), 0.15, (0.0, 1.0, 0.03)),
-                                   (96, 160, 5, (12, 6), 0.45, (0.0, 0.25, 0.0))])
+                                   (96, 160, 5, (12, 6), 0.45, (0.0, 0.25, 0.0)),
+                                   (128, 256, 9, (40, 10), 0.25, (0.4, 1.0, 0.03)),       # same_different_bias != 0:
+                                   (96, 160, 5, (12, 6), 0.45, (-0.7, 0.5, 0.01))])        # glibc's expf restated too
 def test_exact_phase_a_is_bit_identical_to_the_oracle(oracle, shape):
     """Arg-max class, per-record log-odds (logf(p) - (float)log(1 - p), segment.cc:33-36) and initial
-    priority (segment.cc:107-150) of EVERY record: identical bits (NaN where the edge leaves the image)."""
+    priority (segment.cc:107-150) of EVERY record: identical bits (NaN where the edge leaves the image) --
+    also with same_different_bias != 0, whose logit / sigmoid round trip goes through the C library's logf,
+    log and expf in the reference (segment.cc:183-195; mn_ref_logf / mn_ref_expf here)."""
     import torch
     H, W, C, oa, noise, opts = shape
     offs = synth.generate_offsets(*oa)
@@ -373,6 +377,34 @@ def test_pair_table_slots_stay_consistent_when_inserts_move_occupants(oracle, mo
     m = re.search(r"pair-table check: (\d+) errors \(slow inserts (\d+)\)", capfd.readouterr().err)
     assert m and int(m.group(1)) == 0 and int(m.group(2)) > 1000, m
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_paranoid_build_gives_the_same_masks_and_step_counts():
+    """The exact engine's loop issues its global loads and stores from ONE wave without fences and relies on the
+    memory pipeline keeping accesses to one address in program order (mn_kernels_exact.h).
+    libmergenet_hip_paranoid.so (-DMN_X_PARANOID, built by the same Makefile) waits for every outstanding
+    vector-memory operation after each pass and step instead: the two builds must give identical masks,
+    partitions, class lists and step / merge / tie counts."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paranoid = os.path.join(root, "mergenet_amd", "libmergenet_hip_paranoid.so")
+    assert os.path.exists(paranoid), "make -C mergenet_amd/csrc builds it"
+    names = ["cseg_blur_64x128_r2", "cseg_crowd48_256x512_s6400"]
+    outs = []
+    for lib in (None, paranoid):
+        env = dict(os.environ)
+        env.pop("MN_LIB", None)
+        if lib:
+            env["MN_LIB"] = lib
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_exact_digest.py")] + names,
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["lib"] == "libmergenet_hip.so" and outs[1]["lib"] == "libmergenet_hip_paranoid.so"
+    for n in names:
+        assert outs[0][n] == outs[1][n], (n, outs[0][n], outs[1][n])
 
 
 def test_tied_pops_are_counted():

@@ -52,16 +52,6 @@ def test_golden_csegment_tie_dominated_exact_mode(oracle, name):
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
 
 
-@pytest.mark.xfail(strict=True, reason="the small-list finisher (debug_flags bit 8: round 2's exact mode) breaks "
-                   "ties by (lowest u, lowest v) and differs from the reference on this input; kept as the "
-                   "witness that the tie rule matters")
-@pytest.mark.parametrize("name", sorted(TIE_DOMINATED))
-def test_golden_csegment_tie_dominated_old_finisher(oracle, name):
-    g = gu.load(name)
-    mask, classes, part, stats = _run(g, seg.MN_MODE_EXACT, debug_flags=seg.MN_DEBUG_OLD_EXACT)
-    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
-
-
 # ---- order-dependent inputs (round 2): vectors from the reference's own segment.cc ------------------
 # What is PROVEN equal to the reference's sequential order is EXACT mode; the fast modes are
 # approximations of that order on such inputs and say so (certified == 0).  The strict xfails
@@ -96,35 +86,21 @@ def test_order_dependent_goldens_speculative_path_known_gap(oracle, name):
 
 def test_crowded_48_instance_goldens(oracle):
     """256x512 images crowded with 48 overlapping instances (slivers of a few pixels): seed 6400 equals
-    the reference in every mode.  Seed 6408 is sign-separable but order-dependent in its second phase
-    (which small instances the background swallows): components mode and -- since the rounds contract
-    order-free clusters the same way -- the rounds start that phase from fresh priorities where the
-    reference's records are stale, and merge one instance more (strict xfails above and below);
-    neither result is proven (proof == 0), and 99.9 % of the pixels agree."""
+    the reference in every mode.  (Seed 6408 is sign-separable but order-dependent in its second phase -- which
+    small instances the background swallows: the speculative components attempt starts that phase from fresh
+    priorities where the reference's records are stale, strict xfail above; AUTO redoes it in the exact
+    engine, tests/test_gpu_exact.py.)"""
     g = gu.load("cseg_crowd48_256x512_s6400")
     for mode in (seg.MN_MODE_AUTO, seg.MN_MODE_ROUNDS):
         mask, classes, part, stats = _run(g, mode)
         assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), (mode, stats)
-    g = gu.load("cseg_crowd48_256x512_s6408")
-    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=seg.MN_DEBUG_CLUSTERS)
-    assert stats["proof"] == 0
-    assert labels.agreement(mask, g["mask"]) >= 0.999 * mask.size
-    assert abs(len(classes) - len(g["object_class"])) <= 1
 
 
-def test_crowded_48_seed_6408_rounds_equal_reference_again(oracle):
-    """Round 2 contracted order-free clusters of objects by default and lost this vector; the contraction
-    is opt-in now (debug_flags bit 9) and the default rounds equal the reference here as in round 1."""
+def test_crowded_48_seed_6408_rounds_equal_reference(oracle):
+    """The explicit rounds (from the cores, no contraction of object clusters: round 2's contraction started the
+    second phase from fresh priorities, lost this vector and was removed in round 4) equal the reference here."""
     g = gu.load("cseg_crowd48_256x512_s6408")
     mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS)
-    assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
-
-
-@pytest.mark.xfail(strict=True, reason="known gap of the OPT-IN cluster contraction (debug_flags bit 9): the second "
-                   "phase of a sign-separable but order-dependent map then starts from fresh priorities")
-def test_crowded_48_seed_6408_rounds_with_cluster_contraction_known_gap(oracle):
-    g = gu.load("cseg_crowd48_256x512_s6408")
-    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=seg.MN_DEBUG_CLUSTERS)
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
 
 
@@ -141,9 +117,10 @@ def test_rounds_without_cluster_contraction_equal_reference(oracle, name):
 
 @pytest.mark.parametrize("name", ["cseg_synth_512x1024_s1000", "cseg_synth_256x512"])
 def test_rounds_from_single_pixels_equal_reference(oracle, name):
-    """... and so do the rounds of round 1 (no cores, no clusters: debug_flags bits 2 and 3)."""
+    """... and so do the rounds from single pixels (no cores: debug_flags bit 2 -- the form that also serves
+    options the cores cannot, e.g. the Python variant with a bias)."""
     g = gu.load(name)
-    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=12)
+    mask, classes, part, stats = _run(g, seg.MN_MODE_ROUNDS, debug_flags=4)
     assert oracle.masks_equivalent(mask, classes, g["mask"], g["object_class"]), stats
 
 
@@ -488,6 +465,23 @@ def test_components_mode_ragged_widths_match_oracle(oracle, shape):
     assert st["merges"] == ref.stats["n_merges"]
 
 
+@pytest.mark.parametrize("shape", [(64, 1), (64, 2), (60, 3), (1, 64), (128, 1)])
+def test_images_narrower_than_a_lane_group(oracle, shape):
+    """W < 4 with N % 4 == 0 (advisor, round 3): a lane's four linear pixels would span up to four rows, which
+    the sweep's straddling lane does not handle -- such shapes take one pixel per lane.  Whatever mode the image
+    ends in, the result is the oracle's (vertical offsets only make sense here: (1,0), (-2,0), (3,0) / their
+    horizontal twins)."""
+    H, W = shape
+    offs = [(1, 0), (-2, 0), (3, 0)] if W < 4 else [(0, 1), (0, -2), (0, 3)]
+    s = synth.synth_v1(H, W, 3, offs, 31, noise=0.15, num_instances=2)
+    ref = oracle.run_csegment(s.class_probs, s.sameness_probs, 3, offs, 0.0, 1.0, 0.03)
+    for mode in (seg.MN_MODE_COMPONENTS, seg.MN_MODE_EXACT):
+        mask, classes, part, st = _segment(s.class_probs, s.sameness_probs, offs, mode, (0.0, 1.0, 0.03),
+                                           seg.MN_VARIANT_CSEGMENT)
+        assert oracle.masks_equivalent(mask, classes, ref.mask, ref.object_class), (shape, mode, st)
+        assert abs(st["total_logprob"] - ref.total_logprob) <= 1e-5 * abs(ref.total_logprob)
+
+
 def test_components_mode_falls_back_when_not_separable(oracle):
     """Noise 0.45 flips edge signs inside instances: the check must send the image to the rounds."""
     ref, mask, classes, part, st = _components_vs_oracle(oracle, 96, 160, 4, 5, 0.45)
@@ -662,7 +656,7 @@ def test_components_mode_extreme_shapes(oracle, shape):
         # the sweep takes offsets five at a time: offsets 32..34 of the last group do not exist and must
         # not set bits 0..2 (they did: every O >= 31 image then failed the separability check)
         assert st["mode_used"] == seg.MN_MODE_COMPONENTS, st
-        for flags in (0, seg.MN_DEBUG_CLUSTERS):
+        for flags in (0, seg.MN_DEBUG_NO_CORES):
             ctx = seg.HostContext(H, W, C, len(offs))
             try:
                 o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=flags)
@@ -759,7 +753,7 @@ def test_core_with_a_non_positive_edge_inside_falls_apart(oracle):
         sp = maps(bridge)
         ref = oracle.run_csegment(cp, sp, C, offs, 0.0, 1.0, 0.03)
         ctx = seg.HostContext(H, W, C, len(offs))
-        o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8)
+        o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_ROUNDS, clip_inputs=1)
         mask, classes, part, st = ctx.segment(cp, sp, offs, o)
         ctx.close()
         assert st["status"] == 0 and st["cores_condemned"] == (1 if bridge else 0), st
@@ -782,12 +776,12 @@ def test_blurred_maps_general_path_stays_close_to_the_reference(oracle, name, fl
 
 
 @pytest.mark.parametrize("shape", [(33, 47), (50, 70), (61, 96), (64, 101), (97, 130)])
-@pytest.mark.parametrize("flags", [seg.MN_DEBUG_CLUSTERS, 0])
+@pytest.mark.parametrize("flags", [seg.MN_DEBUG_NO_CORES, 0])
 def test_general_path_on_odd_shapes_equals_oracle(oracle, shape, flags):
     """Widths and pixel counts that are not multiples of 4 (the one-pixel-per-lane forms of the sweep,
-    the separate class sweep, tail lanes of every 4-pixel kernel), through the general path with
-    (flags 512) and without (flags 0) the cluster contraction: separable maps, so the reference's result
-    is expected exactly."""
+    the separate class sweep, tail lanes of every 4-pixel kernel), through the general path from the
+    cores (flags 0) and from single pixels (flags 4): separable maps, so the reference's result is expected
+    exactly."""
     H, W = shape
     offs = synth.generate_offsets(12, 8)
     for seed in (4100, 4101, 4102):

@@ -18,7 +18,7 @@ for n in names:
     line = "%-36s" % n
     for b in bands:
         o = seg.default_options(same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias,
-                                mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, core_radius=b, variant=variant)
+                                mode=seg.MN_MODE_ROUNDS, clip_inputs=1, core_radius=b, variant=variant)
         try:
             mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
             eq = labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])

@@ -22,7 +22,7 @@ import golden_util as gu
 for name in ("cseg_synth_1024x2048_cfg2", "cseg_synth_1024x2048_s1003"):
     g = gu.load(name)
     for fl in (4096, 2048):
-        o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, finish_limit=fl)
+        o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, finish_limit=fl)
         ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
         print("%s finish_limit %d: equal %d  %.2f ms rounds %d steps %d" % (name, fl, labels.masks_equivalent(mask, classes, g["mask"], g["object_class"]),

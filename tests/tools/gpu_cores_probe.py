@@ -14,7 +14,7 @@ small += [n for n in gu.names("cseg_") if ("n35" in n or "n60" in n or "noise" i
 
 
 def run(ctx, g, flags, **kw):
-    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, core_radius=flags, **kw)
+    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, core_radius=flags, **kw)
     mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
     eq = labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])
     agree = labels.agreement(mask, g["mask"])
@@ -45,7 +45,7 @@ s = synth.blurred_v1(1024, 2048, 9, offs, 4242, radius=2, noise=0.05)
 ctx = seg.HostContext(1024, 2048, 9, 10)
 res = {}
 for flags, tag in ((-1, "strict"), (10, "r10   "), (6, "r6    ")):
-    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, debug_flags=8, core_radius=flags)
+    o = seg.default_options(mode=seg.MN_MODE_ROUNDS, clip_inputs=1, core_radius=flags)
     ctx.segment(s.class_probs, s.sameness_probs, offs, o)
     mask, classes, part, st = ctx.segment(s.class_probs, s.sameness_probs, offs, o)
     res[tag] = mask
