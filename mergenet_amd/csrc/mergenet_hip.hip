@@ -994,7 +994,7 @@ static int exact_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t s
     for (int i = 0; i < n; i++) {
       const XState& X = cs[i]->xw.X;
       hx[i] = X;
-      const size_t l = (size_t)X.NBpad * 8 + (size_t)X.NG * 8 + 128 * 4 + 8 * 4 + 2048 * 4 + (size_t)MN_X_TSTACK * 8 + 64;
+      const size_t l = MN_X_LDS_BYTES(X.NBpad);
       if (l > lds) lds = l;
       // every wave reaches the loop exit: the reference needs ~0.4 steps per initial record; 8 per
       // record (plus slack) is the hard stop of a run, whatever the input

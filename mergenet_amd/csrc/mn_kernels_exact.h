@@ -40,6 +40,19 @@
 #define MN_X_DIRTY 0xFFFFFFFFFFFFFFFFull
 #define MN_X_MAXBLOCKS 16384
 #define MN_X_TSTACK 1024
+// LDS layout of mn_x_run (bytes)
+#define MN_X_LDS_GMASK 512
+#define MN_X_LDS_CNT (MN_X_LDS_GMASK + 32)
+#define MN_X_LDS_TIE (MN_X_LDS_CNT + 32)
+#define MN_X_LDS_CTAB (MN_X_LDS_TIE + 32)
+#define MN_X_LDS_STK (MN_X_LDS_CTAB + 2048 * 4)
+#define MN_X_LDS_L2 (MN_X_LDS_STK + MN_X_TSTACK * 8)
+#define MN_X_LDS_L1 (MN_X_LDS_L2 + (MN_X_MAXBLOCKS / 64) * 8)
+#define MN_X_LDS_BYTES(nbpad) ((size_t)MN_X_LDS_L1 + (size_t)(nbpad) * 8)
+// sh_cnt slots
+enum { MN_XC_RESCANS = 0, MN_XC_REALLOCS, MN_XC_FOLDED, MN_XC_ADOPTED, MN_XC_SLOW, MN_XC_TIEDMERGES };
+// sh_tie slots
+enum { MN_XT_DEPTH = 0, MN_XT_PAIRS, MN_XT_TIED, MN_XT_TOPW };
 
 enum { MN_X_RUNNING = 0, MN_X_DONE = 1, MN_X_BUDGET = 2, MN_X_ARENA_FULL = 3, MN_X_HASH_FULL = 4 };
 
@@ -381,48 +394,45 @@ __global__ __launch_bounds__(64) void mn_x_build_l1(XState X) {
 #define MN_X_MEM_SYNC() asm volatile("" ::: "memory")
 #endif
 
-// maximum (word, lowest record) of one block of leaves, `skip` left out; the whole wave, 16-byte loads,
-// no branches: the words first (one v_max per leaf), then the lowest id among the holders of the
-// maximum.  The leaf array is padded by 1024 words, so that a block shorter than a round of loads reads
-// (and ignores) what follows it.
+// maximum (word, lowest record) of one block of leaves; the whole wave, 16-byte loads, the words first (one
+// v_max3 per two leaves), then the lowest id among the holders of the maximum.  The block size is uniform over
+// the wave: loads beyond a short block are skipped by scalar branches (no per-lane masks).  The popped record
+// is taken out of its block BEFORE the scan by storing 0 in its leaf (the wave's store precedes its loads of
+// the same address; the leaf gets its new word -- or stays 0 -- later in the step).
 struct __attribute__((packed, aligned(4))) mn_x_f4u { float x, y, z, w; };   // 16-byte load, 4-byte aligned
 
 template <bool WITH_REC>
-__device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned base, int B, unsigned skip,
-                                               int lane, const XRec* recp, uint4* rec_out) {
+__device__ __forceinline__ u64 mn_x_scan_block(const unsigned* leaf, unsigned base, int B, int lane,
+                                               const XRec* recp, uint4* rec_out) {
   unsigned best = 0u;
   unsigned bestid = MN_X_INVALID;
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
   for (int i0 = 0; i0 < B; i0 += 1024) {
-    uint4 w[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      w[j] = *reinterpret_cast<const uint4*>(leaf + base + (unsigned)(i0 + j * 256 + lane * 4));
+    const unsigned* p = leaf + base + (unsigned)(i0 + lane * 4);
+    uint4 w0 = *reinterpret_cast<const uint4*>(p), w1 = zero, w2 = zero, w3 = zero;
+    if (B > 256) w1 = *reinterpret_cast<const uint4*>(p + 256);
+    if (B > 512) { w2 = *reinterpret_cast<const uint4*>(p + 512); w3 = *reinterpret_cast<const uint4*>(p + 768); }
     // (the popped record's own entry: issued BEHIND the leaf loads, so that the wait for the leaves
     //  does not wait for it and the two round trips overlap)
     if (WITH_REC && i0 == 0) *rec_out = *reinterpret_cast<const uint4*>(recp);
-    unsigned m = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int i = i0 + j * 256 + lane * 4;
-      const unsigned id = base + (unsigned)i;
-      const bool in = i < B;
-      w[j].x = (in && id != skip) ? w[j].x : 0u;
-      w[j].y = (in && id + 1 != skip) ? w[j].y : 0u;
-      w[j].z = (in && id + 2 != skip) ? w[j].z : 0u;
-      w[j].w = (in && id + 3 != skip) ? w[j].w : 0u;
-      m = max(max(m, w[j].x), max(max(w[j].y, w[j].z), w[j].w));
+    const unsigned m0 = max(max(w0.x, w0.y), max(w0.z, w0.w)), m1 = max(max(w1.x, w1.y), max(w1.z, w1.w));
+    const unsigned m2 = max(max(w2.x, w2.y), max(w2.z, w2.w)), m3 = max(max(w3.x, w3.y), max(w3.z, w3.w));
+    const unsigned m = max(max(m0, m1), max(m2, m3));
+    if (m > best) {                                // (later rounds hold higher ids: ties stay with the earlier)
+      best = m;
+      // lowest id of this round holding its maximum (descending, so that the lowest wins)
+      const unsigned id = base + (unsigned)(i0 + lane * 4);
+      unsigned mid = MN_X_INVALID;
+      mid = (w3.w == m) ? id + 771 : mid; mid = (w3.z == m) ? id + 770 : mid;
+      mid = (w3.y == m) ? id + 769 : mid; mid = (w3.x == m) ? id + 768 : mid;
+      mid = (w2.w == m) ? id + 515 : mid; mid = (w2.z == m) ? id + 514 : mid;
+      mid = (w2.y == m) ? id + 513 : mid; mid = (w2.x == m) ? id + 512 : mid;
+      mid = (w1.w == m) ? id + 259 : mid; mid = (w1.z == m) ? id + 258 : mid;
+      mid = (w1.y == m) ? id + 257 : mid; mid = (w1.x == m) ? id + 256 : mid;
+      mid = (w0.w == m) ? id + 3 : mid; mid = (w0.z == m) ? id + 2 : mid;
+      mid = (w0.y == m) ? id + 1 : mid; mid = (w0.x == m) ? id : mid;
+      bestid = mid;
     }
-    // lowest id of this round holding its maximum (descending, so that the lowest wins)
-    unsigned mid = MN_X_INVALID;
-#pragma unroll
-    for (int j = 3; j >= 0; j--) {
-      const unsigned id = base + (unsigned)(i0 + j * 256 + lane * 4);
-      mid = (w[j].w == m) ? id + 3 : mid;
-      mid = (w[j].z == m) ? id + 2 : mid;
-      mid = (w[j].y == m) ? id + 1 : mid;
-      mid = (w[j].x == m) ? id : mid;
-    }
-    if (m > best) { best = m; bestid = mid; }      // (later rounds hold higher ids: ties stay with the earlier)
   }
   const unsigned mw = mn_x_wmax_u32(best);
   if (mw == 0u) return 0ull;
@@ -490,39 +500,61 @@ __device__ __forceinline__ bool mn_x_tie_rival_lane(const u64* stk, int depth, u
 __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps, const XState* __restrict__ Xs,
                                                long long budget) {
   const ImgParams& P = Ps[blockIdx.x];
-  const XState X = Xs[blockIdx.x];
+  // (the loop is short of scalar registers -- 106 SGPRs with ~100 spills to vector lanes: fields the loop does
+  //  not use stay behind the pointer and are loaded where they are needed)
+  const XState* __restrict__ Xc = Xs + blockIdx.x;
+  struct { XRec* rec; unsigned* leaf; XSlot* hs; unsigned bmask; XObj* obj; int* acap; float* lp; int* parent;
+           unsigned* arena; unsigned* ostamp; int Blog, NG; XCtl* ctl; } X;
+  X.rec = Xc->rec; X.leaf = Xc->leaf; X.hs = Xc->hs; X.bmask = Xc->bmask; X.obj = Xc->obj; X.acap = Xc->acap;
+  X.lp = Xc->lp; X.parent = Xc->parent; X.arena = Xc->arena; X.ostamp = Xc->ostamp; X.Blog = Xc->Blog;
+  X.NG = Xc->NG; X.ctl = Xc->ctl;
   {
     // (a relaunch of the batch: this image has finished, or waits for a larger workspace)
     const int st0 = X.ctl->status;
     if (st0 != MN_X_RUNNING && st0 != MN_X_BUDGET) return;
   }
+  // LDS layout: the small arrays at FIXED offsets (no scalar registers for their addresses), the block maxima last
   extern __shared__ __attribute__((aligned(16))) unsigned char x_smem[];
-  u64* l1 = reinterpret_cast<u64*>(x_smem);                        // [NBpad]
-  u64* l2 = l1 + X.NBpad;                                          // [NG]
-  float* sh_lpa = reinterpret_cast<float*>(l2 + X.NG);             // [128] survivor's new class vector
-  unsigned* sh_gmask = reinterpret_cast<unsigned*>(sh_lpa + 128);  // [8] groups that lost a maximum
-  unsigned* sh_ctab = sh_gmask + 8;                                // [2048] same-slot check of a pass's inserts
-  u64* sh_stk = reinterpret_cast<u64*>(sh_ctab + 2048);            // [MN_X_TSTACK] nesting stack (ties)
+  float* sh_lpa = reinterpret_cast<float*>(x_smem);                               // [128] survivor's new class vector
+  unsigned* sh_gmask = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_GMASK);      // [8] groups that lost a maximum
+  unsigned* sh_cnt = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_CNT);          // [8] diagnostic counters of the launch
+  int* sh_tie = reinterpret_cast<int*>(x_smem + MN_X_LDS_TIE);                    // [8] tie tracking: depth, pairs, tied entries, top word
+  unsigned* sh_ctab = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_CTAB);        // [2048] same-slot check of a pass's inserts
+  u64* sh_stk = reinterpret_cast<u64*>(x_smem + MN_X_LDS_STK);                    // [MN_X_TSTACK] nesting stack (ties)
+  u64* l2 = reinterpret_cast<u64*>(x_smem + MN_X_LDS_L2);                         // [MN_X_MAXBLOCKS / 64] group maxima
+  u64* l1 = reinterpret_cast<u64*>(x_smem + MN_X_LDS_L1);                         // [NBpad] block maxima
   const int lane = threadIdx.x;
   const int C = P.C;
   const int B = 1 << X.Blog;
 
-  for (int i = lane; i < X.NBpad; i += 64) l1[i] = (i < X.NB) ? X.l1g[i] : 0ull;
-  if (lane < 8) sh_gmask[lane] = 0u;
+  for (int i = lane; i < Xc->NBpad; i += 64) l1[i] = (i < Xc->NB) ? Xc->l1g[i] : 0ull;
+  if (lane < 8) { sh_gmask[lane] = 0u; sh_cnt[lane] = 0u; }
+  for (int i = lane; i < MN_X_MAXBLOCKS / 64; i += 64) l2[i] = 0ull;
   MN_X_LDS_SYNC();
   for (int g = 0; g < X.NG; g++) mn_x_group_refresh(l1, l2, g, lane);
   MN_X_LDS_SYNC();
 
-  long long steps = 0, merges = 0, rescans = 0, reallocs = 0, folded = 0, adopted = 0, slow_inserts = 0;
-  long long tied_steps = 0, tied_merges = 0;
+  // (per-launch counts fit 32 bits: a launch runs at most 2^24 steps of at most a few thousand records each)
+  unsigned steps = 0, merges = 0, tied_steps = 0;     // (the diagnostic counts live in LDS: sh_cnt)
+  const unsigned budget32 = budget > 0x7FFFFFFFll ? 0x7FFFFFFFu : (unsigned)budget;
   // tie-conflict tracking: state of the previous launch
   const long long steps0 = X.ctl->steps;
-  long long tied_conflicts = X.ctl->tied_conflicts;
-  int tdepth = X.ctl->tdepth, tpairs = X.ctl->tpairs, ttied = X.ctl->ttied;
+  const bool ev_overflow = steps0 + (long long)budget32 >= 0x7FFFFFF0ll;
+  const unsigned ev0 = (unsigned)steps0 + 1u;
+  unsigned tied_conflicts = X.ctl->tied_conflicts > 0 ? 1u : 0u;
   bool track = X.ctl->ttrack != 0;
-  for (int i = lane; i < tdepth; i += 64) sh_stk[i] = X.tstack[i];
-  MN_X_LDS_SYNC();
-  unsigned ttopw = tdepth > 0 ? mn_x_te_word(sh_stk[tdepth - 1]) : 0u;
+  {
+    // (the nesting stack's scalars live in LDS and are only read while tracking is on: on maps full of equal
+    //  values the first conflict comes within a few hundred steps and the loop carries one flag from then on)
+    const int d0 = X.ctl->tdepth;
+    for (int i = lane; i < d0; i += 64) sh_stk[i] = Xc->tstack[i];
+    MN_X_LDS_SYNC();
+    if (lane == 0) {
+      sh_tie[MN_XT_DEPTH] = d0; sh_tie[MN_XT_PAIRS] = X.ctl->tpairs; sh_tie[MN_XT_TIED] = X.ctl->ttied;
+      sh_tie[MN_XT_TOPW] = d0 > 0 ? (int)mn_x_te_word(sh_stk[d0 - 1]) : 0;
+    }
+    MN_X_LDS_SYNC();
+  }
   unsigned long long bump = X.ctl->bump;
   int status = X.ctl->status < 0 || X.ctl->status == MN_X_HASH_FULL ? X.ctl->status : MN_X_RUNNING;
 #ifdef MN_X_STAMPS
@@ -534,20 +566,23 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   while (status == MN_X_RUNNING) {
     MN_X_STAMP(0);
     // ---- pop: the largest (word, lowest record id) ----
-    u64 top = 0;
-    for (int g = lane; g < X.NG; g += 64) { const u64 v = l2[g]; top = v > top ? v : top; }
+    // (l2 holds MN_X_MAXBLOCKS / 64 = 256 entries, the unused ones 0: four per lane, kept in registers for the
+    //  tie test below)
+    const u64 q0 = l2[lane], q1 = l2[lane + 64], q2 = l2[lane + 128], q3 = l2[lane + 192];
+    u64 top = q0 > q1 ? q0 : q1;
+    { const u64 t2 = q2 > q3 ? q2 : q3; top = t2 > top ? t2 : top; }
     top = mn_x_wmax_pair(top);
     const unsigned gword = (unsigned)(top >> 32);
     if (gword == 0u) { status = MN_X_DONE; break; }
     if (top == MN_X_DIRTY) { status = MN_ERR_INTERNAL; break; }
-    if (steps >= budget) { status = MN_X_BUDGET; break; }
+    if (steps >= budget32) { status = MN_X_BUDGET; break; }
     const unsigned rid = mn_x_rid(top);
     const unsigned blk = rid >> X.Blog;
     // Is the pop forced?  A second live record with the bit-equal stored priority (in another group of
     // blocks, another block of this group, or -- below -- this block) means the reference's heap decides
     // between them (segment.h:270-275 compares the float only); the engine takes the lowest record id.
-    int eqg = 0;
-    for (int g = lane; g < X.NG; g += 64) eqg += ((unsigned)(l2[g] >> 32) == gword) ? 1 : 0;
+    const int eqg = (((unsigned)(q0 >> 32) == gword) ? 1 : 0) + (((unsigned)(q1 >> 32) == gword) ? 1 : 0) +
+                    (((unsigned)(q2 >> 32) == gword) ? 1 : 0) + (((unsigned)(q3 >> 32) == gword) ? 1 : 0);
     const u64 tg = __ballot(eqg > 0);
     bool tied = (tg & (tg - 1ull)) != 0ull || __ballot(eqg > 1) != 0ull;
     {
@@ -557,7 +592,8 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     MN_X_STAMP(1);
     // the record, and beside it the popped block without it (its maximum changes either way)
     uint4 rraw;
-    const u64 bm = mn_x_scan_block<true>(X.leaf, blk << X.Blog, B, rid, lane, &X.rec[rid], &rraw);
+    if (lane == 0) X.leaf[rid] = 0u;               // (out of its block before the scan; see mn_x_scan_block)
+    const u64 bm = mn_x_scan_block<true>(X.leaf, blk << X.Blog, B, lane, &X.rec[rid], &rraw);
     const u64 key = ((u64)rraw.y << 32) | (u64)rraw.x;
     const float S = __uint_as_float(rraw.z);
     const unsigned slot_r = rraw.w;
@@ -567,9 +603,11 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     MN_X_STAMP(2);
     const int x = mn_key_u(key), y = mn_key_v(key);
     // ---- ties: this pop's place in the nesting of events ----
-    const unsigned long long ev64 = (unsigned long long)(steps0 + steps) + 1ull;
-    const unsigned ev = (unsigned)ev64;
+    const unsigned ev = ev0 + steps;
+    int tdepth = 0, tpairs = 0, ttied = 0;          // (valid while `track`)
     if (track) {
+      tdepth = sh_tie[MN_XT_DEPTH]; tpairs = sh_tie[MN_XT_PAIRS]; ttied = sh_tie[MN_XT_TIED];
+      unsigned ttopw = (unsigned)sh_tie[MN_XT_TOPW];
       while (tdepth > 0 && ttopw > gword) {
         const int j = tdepth - 1 - lane;
         const u64 e = (j >= 0) ? sh_stk[j] : 0ull;
@@ -582,15 +620,18 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
         ttopw = tdepth > 0 ? mn_x_te_word(sh_stk[tdepth - 1]) : 0u;
         if (cnt < 64) break;
       }
-      if (tdepth >= MN_X_TSTACK || ev64 >= 0x7FFFFFF0ull) {
+      if (tdepth >= MN_X_TSTACK || ev_overflow) {
         tied_conflicts++;            // (cannot be followed any further: counted as a conflict, conservatively)
         track = false;
       } else {
         if (tdepth > 0 && ttopw == gword) tpairs++;
         if (lane == 0) sh_stk[tdepth] = ((u64)gword << 32) | ((u64)ev << 1) | (tied ? 1ull : 0ull);
         tdepth++;
-        ttopw = gword;
         ttied += tied ? 1 : 0;
+        if (lane == 0) {
+          sh_tie[MN_XT_DEPTH] = tdepth; sh_tie[MN_XT_PAIRS] = tpairs; sh_tie[MN_XT_TIED] = ttied;
+          sh_tie[MN_XT_TOPW] = (int)gword;
+        }
         MN_X_LDS_SYNC();
       }
     }
@@ -668,27 +709,27 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     int newcap = 0;
     if (la + lb > capa) {
       newcap = ((4 * (la + lb) + 63) / 64) * 64;
-      if (bump + (unsigned long long)newcap > X.arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
+      if (bump + (unsigned long long)newcap > Xc->arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
       newp = (unsigned)bump;
       bump += (unsigned long long)newcap;
       moved = true;
     }
-    if (X.mlog_cap > 0 && lane == 0) {
+    if (Xc->mlog_cap > 0 && lane == 0) {
       const long long at = X.ctl->merges + merges;
-      if (at < X.mlog_cap) {
-        X.mlog[4 * at] = a; X.mlog[4 * at + 1] = b; X.mlog[4 * at + 2] = (int)rid; X.mlog[4 * at + 3] = (int)(gword - 1u);
+      if (at < Xc->mlog_cap) {
+        int* ml = Xc->mlog;
+        ml[4 * at] = a; ml[4 * at + 1] = b; ml[4 * at + 2] = (int)rid; ml[4 * at + 3] = (int)(gword - 1u);
       }
     }
     merges++;
-    tied_merges += tied ? 1 : 0;
+    if (tied && lane == 0) sh_cnt[MN_XC_TIEDMERGES] += 1u;
     // object state of the survivor (:635-642); the absorbed object only keeps its parent link
     if (lane < C) { const float s0 = ax0 + ay0; X.lp[(size_t)a * C + lane] = s0; sh_lpa[lane] = s0; }
     if (lane + 64 < C) { const float s1 = ax1 + ay1; X.lp[(size_t)a * C + lane + 64] = s1; sh_lpa[lane + 64] = s1; }
     const int na = nx + ny;
     if (lane == 0) {
       X.parent[b] = a;
-      X.rec[rid].key = MN_EMPTY;               // the merged record leaves every list (:645-647)
-      X.leaf[rid] = 0u;
+      X.rec[rid].key = MN_EMPTY;               // the merged record leaves every list (:645-647); its leaf is 0 already
       X.hs[slot_r].key = MN_X_HEMPTY;
       l1[blk] = bm;
       sh_gmask[blk >> 11] |= 1u << ((blk >> 6) & 31u);
@@ -708,7 +749,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
         cnt += __popcll(mk);
       }
       pa = newp; la = cnt; capa = newcap;
-      reallocs++;
+      if (lane == 0) sh_cnt[MN_XC_REALLOCS] += 1u;
       if (lane == 0) X.acap[a] = capa;
     }
     const float la_c = sh_lpa[mc];
@@ -822,9 +863,9 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
         while (cm) {
           const int l = __ffsll((long long)cm) - 1;
           cm &= cm - 1ull;
-          slow_inserts++;
+          if (lane == 0) sh_cnt[MN_XC_SLOW] += 1u;
           if (lane == l) {
-            nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St, (X.dbg & 1) != 0);
+            nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St, (Xc->dbg & 1) != 0);
             XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
             *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
           }
@@ -834,8 +875,10 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       }
       MN_X_STAMP(9);
       la += __popcll(am);
-      adopted += __popcll(am);
-      folded += __popcll(__ballot(fold));
+      {
+        const unsigned nfold = (unsigned)__popcll(__ballot(fold));
+        if (lane == 0) { sh_cnt[MN_XC_ADOPTED] += (unsigned)__popcll(am); sh_cnt[MN_XC_FOLDED] += nfold; }
+      }
       // re-score what was touched (:695-698, 703-706) with the survivor's new state
       unsigned w = 0u;
       if (live) {
@@ -909,9 +952,9 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
         while (dm) {
           const unsigned bb = (unsigned)(g * 64 + __ffsll((long long)dm) - 1);
           dm &= dm - 1ull;
-          const u64 v = mn_x_scan_block<false>(X.leaf, bb << X.Blog, B, MN_X_INVALID, lane, nullptr, nullptr);
+          const u64 v = mn_x_scan_block<false>(X.leaf, bb << X.Blog, B, lane, nullptr, nullptr);
           if (lane == 0) l1[bb] = v;
-          rescans++;
+          if (lane == 0) sh_cnt[MN_XC_RESCANS] += 1u;
         }
         MN_X_LDS_SYNC();
         mn_x_group_refresh(l1, l2, g, lane);
@@ -923,17 +966,18 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     MN_X_STAMP(11);
   }
 
-  for (int i = lane; i < tdepth; i += 64) X.tstack[i] = sh_stk[i];
+  for (int i = lane; i < sh_tie[MN_XT_DEPTH]; i += 64) Xc->tstack[i] = sh_stk[i];
   if (lane == 0) {
     XCtl* c = X.ctl;
 #ifdef MN_X_STAMPS
     for (int i = 0; i < 16; i++) c->stamps[i] += st_acc[i];
 #endif
     c->status = status;
-    c->steps += steps; c->merges += merges; c->rescans += rescans; c->reallocs += reallocs;
-    c->folded += folded; c->adopted += adopted; c->slow_inserts += slow_inserts;
-    c->tied_steps += tied_steps; c->tied_merges += tied_merges;
-    c->tied_conflicts = tied_conflicts; c->tdepth = tdepth; c->tpairs = tpairs; c->ttied = ttied;
+    c->steps += steps; c->merges += merges; c->rescans += sh_cnt[MN_XC_RESCANS]; c->reallocs += sh_cnt[MN_XC_REALLOCS];
+    c->folded += sh_cnt[MN_XC_FOLDED]; c->adopted += sh_cnt[MN_XC_ADOPTED]; c->slow_inserts += sh_cnt[MN_XC_SLOW];
+    c->tied_steps += tied_steps; c->tied_merges += sh_cnt[MN_XC_TIEDMERGES];
+    c->tied_conflicts = (long long)tied_conflicts;
+    c->tdepth = sh_tie[MN_XT_DEPTH]; c->tpairs = sh_tie[MN_XT_PAIRS]; c->ttied = sh_tie[MN_XT_TIED];
     c->ttrack = track ? 1 : 0;
     c->bump = bump;
   }

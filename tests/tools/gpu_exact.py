@@ -26,14 +26,15 @@ for name in gu.names("cseg_"):
         continue
     ctx = seg.HostContext(H, W, C, len(g["offsets"]))
     o = seg.default_options(same_different_bias=g["spec"]["opts"][0], object_merge_factor=g["spec"]["opts"][1],
-                            merge_logprob_bias=g["spec"]["opts"][2], mode=seg.MN_MODE_EXACT, clip_inputs=1)
+                            merge_logprob_bias=g["spec"]["opts"][2], mode=seg.MN_MODE_EXACT, clip_inputs=1,
+                            tie_order=int(os.environ.get("MN_TOOL_TIE_ORDER", "0")))
     t = time.time()
     mask, classes, part, st = ctx.segment(g["class_probs"], g["sameness_probs"], g["offsets"], o)
     dt = time.time() - t
     ok = ck.masks_equivalent(mask, classes, g["mask"], g["object_class"])
-    print("%-34s %4dx%-4d %s  %.2f s  steps %d merges %d objects %d inst %d ms_merge %.1f proof %d cert %d" % (
+    print("%-34s %4dx%-4d %s  %.2f s  steps %d merges %d objects %d inst %d ms_merge %.1f proof %d cert %d tied %d conflicts %d" % (
         name, H, W, "OK " if ok else "BAD", dt, st["finisher_steps"], st["merges"], st["num_objects"],
-        st["num_instances"], st["ms_merge"], st["proof"], st["certified"]), flush=True)
+        st["num_instances"], st["ms_merge"], st["proof"], st["certified"], st["tied_steps"], st.get("tied_conflicts", -1)), flush=True)
     if not ok:
         bad.append(name)
     ctx.close()
