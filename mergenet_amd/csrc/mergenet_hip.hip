@@ -150,7 +150,7 @@ struct mn_context {
     XState* d_X;
     int batch_cap;
     int arena_extra;              // arena words per pixel beyond the initial arrays (doubled when a run fills it)
-    int table_shift;              // pair table: buckets = next_pow2(records >> table_shift)
+    int table_permille;           // pair table: load at the start, in thousandths (lowered when a run fills the table)
   } xw;
   // the reference-order loop (mn_options.tie_order = MN_TIES_REFERENCE, mn_kernels_reforder.h)
   struct RWork {
@@ -209,7 +209,7 @@ static void x_free(mn_context* c) {
   const mn_context::XWork keep = c->xw;
   memset(&c->xw, 0, sizeof(c->xw));
   c->xw.d_P = keep.d_P; c->xw.d_X = keep.d_X; c->xw.batch_cap = keep.batch_cap;
-  c->xw.arena_extra = keep.arena_extra; c->xw.table_shift = keep.table_shift;
+  c->xw.arena_extra = keep.arena_extra; c->xw.table_permille = keep.table_permille;
 }
 
 static void r_free(mn_context* c) {
@@ -243,15 +243,16 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   const size_t NB = (NL + B - 1) / B;
   const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
   if (w.arena_extra <= 0) {
-    w.arena_extra = 11 * O + 8;                       // (measured use: 8.6-8.9 entries per pixel and offset at O = 10, 10.3-10.6 at O = 16)
+    w.arena_extra = 10 * O + 8;                       // (measured use: 8.6 entries per pixel and offset at O = 10, doubling reallocation)
     if (const char* e = getenv("MN_X_ARENA_EXTRA")) { const int v = atoi(e); if (v > 0) w.arena_extra = v; }   // (tests)
-    w.table_shift = 1;
+    w.table_permille = 550;
+    if (const char* e = getenv("MN_X_TABLE_PERMILLE")) { const int v = atoi(e); if (v >= 50 && v <= 950) w.table_permille = v; }   // (tests)
   }
-  const size_t nbuckets = next_pow2(((NL + 256) >> w.table_shift) + 1);   // 4 slots each
+  // pair table: 4-slot buckets for a load of table_permille / 1000 at the start (pairs only disappear: it falls)
+  const size_t nbuckets = (size_t)((double)NL * 1000.0 / (4.0 * (double)w.table_permille)) + 64;
   if (nbuckets * 4 >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
-  int cap0 = 64;
-  while (cap0 < 4 * O) cap0 <<= 1;
-  const size_t arena_cap = (size_t)N * cap0 + (size_t)N * (size_t)w.arena_extra + 65536;
+  // (single pixels keep no stored array: the arena only holds what merges allocate)
+  const size_t arena_cap = (size_t)N * (size_t)w.arena_extra + 65536;
   if (arena_cap >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   const size_t ovf_cap = NL / 256 + 4096;
   if (w.n_pix < (size_t)N || w.n_rec < NL || w.n_cls_floats < (size_t)N * C || w.hcap < nbuckets ||
@@ -276,7 +277,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
     X.overflow_cap = (int)ovf_cap;
   }
   XState& X = w.X;
-  X.bmask = (unsigned)(nbuckets - 1);
+  X.nb = (unsigned)nbuckets;
   X.arena_cap = arena_cap;
   X.Blog = 0;
   while (((size_t)1 << X.Blog) < B) X.Blog++;
@@ -284,7 +285,6 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   X.NBpad = (int)((NB + 63) / 64 * 64);
   X.NG = X.NBpad / 64;
   X.NL = (unsigned)NL;
-  X.cap0 = cap0;
   X.parent = c->parent;
   X.dbg = getenv("MN_X_FORCE_RELOCATE") ? 1 : 0;                       // (tests)
   // diagnostic: MN_X_MERGELOG=<file> keeps the sequence of merges (survivor, absorbed, record, priority)
@@ -374,17 +374,11 @@ static int ctx_alloc(mn_context* c) {
   MN_HIP(dev_alloc(c, &c->label, N));
   MN_HIP(dev_alloc(c, &c->mapbuf, N));
   MN_HIP(dev_alloc(c, &c->lpsum, N * (size_t)c->maxC));
-  MN_HIP(dev_alloc(c, &c->lp_acc, N * (size_t)c->maxC));
-  MN_HIP(dev_alloc(c, &c->ball, N));
-  MN_HIP(dev_alloc(c, &c->bsub, N));
   MN_HIP(dev_alloc(c, &c->fin_lists, 3 * (size_t)MN_FIN2_MAXR));
   c->cc_cap_max = next_pow2(N / 8 + 8192);
   if (c->cc_cap_max > c->cap_full) c->cc_cap_max = c->cap_full;
   MN_HIP(dev_alloc(c, &c->cc_tcount, c->cc_cap_max));
   MN_HIP(dev_alloc(c, &c->cc_lcount, c->cc_cap_max));
-  MN_HIP(dev_alloc(c, &c->cc_bits, N));
-  MN_HIP(dev_alloc(c, &c->cc_roots, N));
-  MN_HIP(dev_alloc(c, &c->cc_negbits, N + 16));
   // record lists and record table: sized for what the speculative components attempt can use (records
   // BETWEEN components: at most cc_cap_max); the general rounds, which hold a record per pixel edge,
   // get theirs at first use (ensure_general) -- 0.3 instead of 2.1 GB per 1024x2048 context, and a ring
@@ -496,6 +490,21 @@ extern "C" void mn_destroy(mn_context* c) {
 }
 
 extern "C" size_t mn_workspace_bytes(const mn_context* c) { return c ? c->bytes : 0; }
+
+// What only the fast paths use (fixed-point class sums, best-record slots, edge masks: 100 B per pixel at C = 9) is
+// allocated at their first use: a context that only ever serves the exact engine -- the contexts of a batch
+// (mn_segment_exact_batch), where memory per image bounds the images in flight -- never pays for it.
+static int ensure_fast(mn_context* c) {
+  if (c->lp_acc) return MN_OK;
+  const size_t N = c->N;
+  MN_HIP(dev_alloc(c, &c->lp_acc, N * (size_t)c->maxC));
+  MN_HIP(dev_alloc(c, &c->ball, N));
+  MN_HIP(dev_alloc(c, &c->bsub, N));
+  MN_HIP(dev_alloc(c, &c->cc_bits, N));
+  MN_HIP(dev_alloc(c, &c->cc_roots, N));
+  MN_HIP(dev_alloc(c, &c->cc_negbits, N + 16));
+  return MN_OK;
+}
 
 // The general rounds (and the small-list exact mode) hold a record per pixel edge: their lists and table
 // are allocated when first needed.  Recorded replay graphs hold the old pointers and are dropped.
@@ -956,13 +965,12 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   mn_context::XWork& w = c->xw;
   XState& X = w.X;
   const size_t N = (size_t)P.N;
-  MN_HIP(hipMemsetAsync(X.hs, 0xFF, ((size_t)X.bmask + 1) * 4 * sizeof(XSlot), st));
-  MN_HIP(hipMemsetAsync(X.arena, 0xFF, N * (size_t)X.cap0 * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.hs, 0xFF, (size_t)X.nb * 4 * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.leaf, 0, (((size_t)X.NB << X.Blog) + 1024) * sizeof(unsigned), st));
   MN_HIP(hipMemsetAsync(X.ostamp, 0, N * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
   w.h_ctl->ttrack = getenv("MN_X_NO_TIE_TRACKING") ? 0 : 1;          // (timing comparisons)
-  w.h_ctl->bump = (unsigned long long)N * (unsigned long long)X.cap0;
+  w.h_ctl->bump = 0ull;
   MN_HIP(hipMemcpyAsync(X.ctl, w.h_ctl, sizeof(XCtl), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(mn_x_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->cls0);
   MN_HIP(hipEventRecord(c->ev[1], st));
@@ -1080,7 +1088,7 @@ static int exact_run(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st
       if (!full[i]) continue;
       mn_context::XWork& w = sub[i]->xw;
       if (full[i] == MN_X_ARENA_FULL) w.arena_extra *= 2;
-      else if (w.table_shift > 0) w.table_shift--;
+      else if (w.table_permille > 100) w.table_permille = w.table_permille * 2 / 3;
       else { rc = MN_ERR_CAPACITY; break; }
       sub[k] = sub[i]; subP[k] = subP[i]; k++;
     }
@@ -1097,7 +1105,7 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
   const size_t N = (size_t)P.N;
   if (getenv("MN_X_CHECK_SLOTS") && c->tie_used != MN_TIES_REFERENCE) {
     // tests: records and pair-table slots must point at each other at the end of a run
-    const size_t n = (size_t)X.NL > ((size_t)X.bmask + 1) * 4 ? (size_t)X.NL : ((size_t)X.bmask + 1) * 4;
+    const size_t n = (size_t)X.NL > (size_t)X.nb * 4 ? (size_t)X.NL : (size_t)X.nb * 4;
     hipLaunchKernelGGL(mn_x_check_slots, dim3(grid_for(n, 256)), dim3(256), 0, st, X);
     long long errs = -1;
     MN_HIP(hipMemcpyAsync(&errs, &X.ctl->slot_errors, sizeof(errs), hipMemcpyDeviceToHost, st));
@@ -1452,6 +1460,10 @@ static int segment_attempt(mn_context* c, const float* d_class_pred, int class_d
   fills.add(c->cnt, sizeof(Counters), 0);
   fills.add(c->scalars, MN_NSCALARS * sizeof(int), 0);
   speculate = speculate && mode == MN_MODE_COMPONENTS && finish_limit <= MN_FIN2_MAXR;
+  if (!xengine) {
+    rc = ensure_fast(c);
+    if (rc != MN_OK) return rc;
+  }
   // everything but the speculative components attempt and the exact engine works on full-size record lists
   if (!speculate && !xengine) {
     rc = ensure_general(c);
@@ -2008,6 +2020,8 @@ extern "C" int mn_score_device(mn_context* c, const float* d_class_pred, int cla
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
   c->debug_flags = opts->debug_flags;
+  rc = ensure_fast(c);
+  if (rc != MN_OK) return rc;
   rc = run_phase_a(c, P, st, true);
   if (rc != MN_OK) return rc;
   if (d_cls_out) MN_HIP(hipMemcpyAsync(d_cls_out, c->ocls, P.N, hipMemcpyDeviceToDevice, st));
@@ -2040,6 +2054,7 @@ extern "C" int mn_sweep_device(mn_context* c, const float* d_class_pred, int cla
   ImgParams P;
   fill_params(&P, d_class_pred, d_adj_pred, offset_dim, W, H, num_classes, offset_list, opts);
   const int N = P.N;
+  if (ensure_fast(c) != MN_OK) return MN_ERR_NO_DEVICE;
   c->debug_flags = opts->debug_flags | 2;          // (no events)
   c->ext_events = 0;
   c->cc_clean = 0;
@@ -2087,6 +2102,7 @@ extern "C" int mn_sweep_time_device(mn_context* c, const float* const* d_class_p
   if (rc != MN_OK) { g_last_status = rc; return rc; }
   MN_HIP(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ensure_fast(c) != MN_OK) return MN_ERR_NO_DEVICE;
   c->debug_flags = opts->debug_flags | 2;          // (no events inside)
   c->ext_events = 0;
   c->cc_clean = 0;

@@ -23,7 +23,10 @@
 //               them); the fold look-ups of a merge run in parallel lanes
 //   * adjacency = one contiguous array of record ids per object in an arena; a merge walks ONLY the
 //               absorbed object's array (64 records per pass) and appends the re-keyed records to the
-//               survivor's (doubling reallocation, dead entries dropped on the way)
+//               survivor's (doubling reallocation, dead entries dropped on the way).  A single PIXEL's array is
+//               IMPLICIT: its records are p * O + k (the pixel as source) and (p - offset k) * O + k (as
+//               target) -- nothing is stored, and half of all merges (those that absorb a single pixel) read
+//               no adjacency memory at all; an object gets a stored array at its first merge as survivor
 // One wavefront runs the loop: no barriers, cross-lane traffic by ballot / shuffle / LDS.  Several
 // images can run side by side on different CUs (one context each).
 //
@@ -40,11 +43,13 @@
 #define MN_X_DIRTY 0xFFFFFFFFFFFFFFFFull
 #define MN_X_MAXBLOCKS 16384
 #define MN_X_TSTACK 1024
+#define MN_X_IMPLICIT 0xFFFFFFFFu   /* XObj.aptr of a single pixel: the array is computed, not stored */
 // LDS layout of mn_x_run (bytes)
 #define MN_X_LDS_GMASK 512
 #define MN_X_LDS_CNT (MN_X_LDS_GMASK + 32)
 #define MN_X_LDS_TIE (MN_X_LDS_CNT + 32)
-#define MN_X_LDS_CTAB (MN_X_LDS_TIE + 32)
+#define MN_X_LDS_OFF (MN_X_LDS_TIE + 32)          /* [2 * MN_MAX_OFFSETS] ints */
+#define MN_X_LDS_CTAB (MN_X_LDS_OFF + 2 * MN_MAX_OFFSETS * 4)
 #define MN_X_LDS_STK (MN_X_LDS_CTAB + 2048 * 4)
 #define MN_X_LDS_L2 (MN_X_LDS_STK + MN_X_TSTACK * 8)
 #define MN_X_LDS_L1 (MN_X_LDS_L2 + (MN_X_MAXBLOCKS / 64) * 8)
@@ -97,8 +102,8 @@ struct __attribute__((aligned(16))) XObj {
 struct XState {
   XRec* rec;                  // [NL] indexed by record id (pixel * O + k)
   unsigned* leaf;             // [NB << Blog] queue word of the stored priority: 0 = not queued
-  XSlot* hs;                  // pair table: (bmask + 1) buckets of 4 slots
-  unsigned bmask;
+  XSlot* hs;                  // pair table: nb buckets of 4 slots
+  unsigned nb;
   XObj* obj;                  // [N]
   int* acap;                  // [N] adjacency entries owned
   float* lp;                  // [N][C] Object::class_logprobs (float32 sums, segment.cc:640)
@@ -110,7 +115,6 @@ struct XState {
   u64* l1g;                   // block maxima in HBM (built by mn_x_build_l1, loaded into LDS)
   int Blog, NB, NBpad, NG;
   unsigned NL;                // record ids in use (N * O)
-  int cap0;                   // arena entries every pixel starts with
   int* mlog;                  // diagnostic (MN_X_MERGELOG): 4 ints per merge {survivor, absorbed, record, priority bits}
   long long mlog_cap;         // merges the log holds (0: none)
   int dbg;                    // bit 0 (MN_X_FORCE_RELOCATE, tests): a slow insert moves an occupant whenever it can
@@ -199,12 +203,12 @@ __device__ __forceinline__ u64 mn_hash64(u64 k) {
   k ^= k >> 33;
   return k;
 }
-// the two buckets of a key
-__device__ __forceinline__ void mn_x_buckets(u64 key, unsigned bmask, unsigned* b1, unsigned* b2) {
+// the two buckets of a key (any bucket count: multiply-high range reduction of the two hash halves)
+__device__ __forceinline__ void mn_x_buckets(u64 key, unsigned nb, unsigned* b1, unsigned* b2) {
   const u64 h = mn_hash64(key);
-  const unsigned x = (unsigned)h & bmask;
-  unsigned y = (unsigned)(h >> 32) & bmask;
-  if (y == x) y = (y ^ 1u) & bmask;
+  const unsigned x = __umulhi((unsigned)h, nb);
+  unsigned y = __umulhi((unsigned)(h >> 32), nb);
+  if (y == x) y = (x + 1u == nb) ? 0u : x + 1u;
   *b1 = x; *b2 = y;
 }
 
@@ -244,10 +248,10 @@ __device__ __forceinline__ float mn_x_score1(const ImgParams& P, const float* la
 // Insertion by ONE lane with everything read afresh (the rare paths: a record the parallel set-up could
 // not place, or a lane of a merge pass that lost its slot to another lane): a free slot of either
 // bucket, else one occupant is moved to ITS other bucket.  Returns the slot, MN_X_INVALID if no room.
-__device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned bmask, u64 key, unsigned rid, float S,
+__device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned nb, u64 key, unsigned rid, float S,
                                                   bool relocate_first = false) {
   unsigned b1, b2;
-  mn_x_buckets(key, bmask, &b1, &b2);
+  mn_x_buckets(key, nb, &b1, &b2);
   XSlot ns; ns.key = key; ns.rid = rid; ns.S = S;
   for (int t = 0; t < 8 && !relocate_first; t++) {
     const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
@@ -258,7 +262,7 @@ __device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned
     const XSlot v = hs[s];
     if (v.key == MN_X_HEMPTY) continue;          // (relocate_first: free slots are taken by the last loop)
     unsigned v1, v2;
-    mn_x_buckets(v.key, bmask, &v1, &v2);
+    mn_x_buckets(v.key, nb, &v1, &v2);
     const unsigned alt = ((s >> 2) == v1) ? v2 : v1;
     for (int q = 0; q < 4; q++)
       if (hs[alt * 4 + q].key == MN_X_HEMPTY) {
@@ -289,16 +293,16 @@ __global__ __launch_bounds__(256) void mn_x_init_objects(ImgParams P, XState X,
     if (c == 0 || l > best) { best = l; bc = c; }
   }
   XObj o;
-  o.size = 1; o.cls = bc; o.aptr = (unsigned)p * (unsigned)X.cap0; o.alen = 2 * P.O;
+  o.size = 1; o.cls = bc; o.aptr = MN_X_IMPLICIT; o.alen = 2 * P.O;
   X.obj[p] = o;
-  X.acap[p] = X.cap0;
+  X.acap[p] = 0;
   X.parent[p] = p;
   cls0[p] = (unsigned char)bc;
 }
 
 // AdjacencyRecord ctor + the constructor's loop (segment.cc:24-46, 209-231): one lane per
-// (pixel, offset); records its key, log-odds, initial priority word, table slot and its two
-// adjacency entries (slot k of the source pixel, slot O + k of the target pixel)
+// (pixel, offset); records its key, log-odds, initial priority word and table slot (its two adjacency
+// entries -- slot k of the source pixel, slot O + k of the target pixel -- are implicit: mn_x_entry)
 __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)P.N * P.O) return;
@@ -324,7 +328,18 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
                                1, 1, oml, &mc);
   const u64 key = mn_key(a, b);
   unsigned b1, b2;
-  mn_x_buckets(key, X.bmask, &b1, &b2);
+  mn_x_buckets(key, X.nb, &b1, &b2);
+  // balanced placement: the bucket with more free slots first (the table starts at a load of 0.55; first-fit in
+  // the first bucket left every tenth record without a slot at that load, two choices leave a few dozen)
+  {
+    int f1 = 0, f2 = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      f1 += (X.hs[b1 * 4 + t].key == MN_X_HEMPTY) ? 1 : 0;
+      f2 += (X.hs[b2 * 4 + t].key == MN_X_HEMPTY) ? 1 : 0;
+    }
+    if (f2 > f1) { const unsigned t = b1; b1 = b2; b2 = t; }
+  }
   unsigned slot = MN_X_INVALID;
   for (int t = 0; t < 8 && slot == MN_X_INVALID; t++) {
     const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
@@ -340,8 +355,6 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
   R.key = key; R.S = oml; R.slot = slot;
   X.rec[rid] = R;
   X.leaf[rid] = mn_x_word(pr);
-  X.arena[(size_t)p * X.cap0 + k] = rid;
-  X.arena[(size_t)q * X.cap0 + P.O + k] = rid;
 }
 
 // the few records both of whose buckets were full when the set-up kernel came by: one lane, one by one
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64) void mn_x_place_overflow(XState X) {
   for (int i = 0; i < n; i++) {
     const unsigned rid = X.overflow[i];
     const XRec R = X.rec[rid];
-    const unsigned s = mn_x_insert_slow(X.hs, X.rec, X.bmask, R.key, rid, R.S);
+    const unsigned s = mn_x_insert_slow(X.hs, X.rec, X.nb, R.key, rid, R.S);
     if (s == MN_X_INVALID) { X.ctl->status = MN_X_HASH_FULL; return; }
     X.rec[rid].slot = s;
   }
@@ -495,6 +508,21 @@ __device__ __forceinline__ bool mn_x_tie_rival_lane(const u64* stk, int depth, u
   return lo < depth && mn_x_te_word(stk[lo]) == w;
 }
 
+// Entry j of an object's adjacency array: stored (arena) or, for a single pixel `o`, computed: j < O the record
+// of the pixel as source of offset j (dead -- key MN_EMPTY -- if that edge leaves the image), else the record
+// whose TARGET it is under offset j - O.  sh_off: {d_row, d_col} per offset, in LDS.
+__device__ __forceinline__ unsigned mn_x_entry(const unsigned* __restrict__ arena, unsigned aptr, int j, int len, int o,
+                                              int O, int W, int H, const int* sh_off) {
+  if (j >= len) return MN_X_INVALID;
+  if (aptr != MN_X_IMPLICIT) return arena[(size_t)aptr + j];
+  if (j < O) return (unsigned)o * (unsigned)O + (unsigned)j;
+  const int k = j - O;
+  const int r = o / W, c = o - r * W;
+  const int rr = r - sh_off[2 * k], cc = c - sh_off[2 * k + 1];
+  if (rr < 0 || rr >= H || cc < 0 || cc >= W) return MN_X_INVALID;
+  return (unsigned)(rr * W + cc) * (unsigned)O + (unsigned)k;
+}
+
 // One workgroup (= one wavefront) per image: block b runs the loop of image b of a batch (images are
 // independent; the reference scales the same way, by processes).
 __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps, const XState* __restrict__ Xs,
@@ -503,9 +531,9 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   // (the loop is short of scalar registers -- 106 SGPRs with ~100 spills to vector lanes: fields the loop does
   //  not use stay behind the pointer and are loaded where they are needed)
   const XState* __restrict__ Xc = Xs + blockIdx.x;
-  struct { XRec* rec; unsigned* leaf; XSlot* hs; unsigned bmask; XObj* obj; int* acap; float* lp; int* parent;
+  struct { XRec* rec; unsigned* leaf; XSlot* hs; unsigned nb; XObj* obj; int* acap; float* lp; int* parent;
            unsigned* arena; unsigned* ostamp; int Blog, NG; XCtl* ctl; } X;
-  X.rec = Xc->rec; X.leaf = Xc->leaf; X.hs = Xc->hs; X.bmask = Xc->bmask; X.obj = Xc->obj; X.acap = Xc->acap;
+  X.rec = Xc->rec; X.leaf = Xc->leaf; X.hs = Xc->hs; X.nb = Xc->nb; X.obj = Xc->obj; X.acap = Xc->acap;
   X.lp = Xc->lp; X.parent = Xc->parent; X.arena = Xc->arena; X.ostamp = Xc->ostamp; X.Blog = Xc->Blog;
   X.NG = Xc->NG; X.ctl = Xc->ctl;
   {
@@ -519,6 +547,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   unsigned* sh_gmask = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_GMASK);      // [8] groups that lost a maximum
   unsigned* sh_cnt = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_CNT);          // [8] diagnostic counters of the launch
   int* sh_tie = reinterpret_cast<int*>(x_smem + MN_X_LDS_TIE);                    // [8] tie tracking: depth, pairs, tied entries, top word
+  int* sh_off = reinterpret_cast<int*>(x_smem + MN_X_LDS_OFF);                    // [2 * O] offsets (d_row, d_col): implicit adjacency
   unsigned* sh_ctab = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_CTAB);        // [2048] same-slot check of a pass's inserts
   u64* sh_stk = reinterpret_cast<u64*>(x_smem + MN_X_LDS_STK);                    // [MN_X_TSTACK] nesting stack (ties)
   u64* l2 = reinterpret_cast<u64*>(x_smem + MN_X_LDS_L2);                         // [MN_X_MAXBLOCKS / 64] group maxima
@@ -529,6 +558,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
 
   for (int i = lane; i < Xc->NBpad; i += 64) l1[i] = (i < Xc->NB) ? Xc->l1g[i] : 0ull;
   if (lane < 8) { sh_gmask[lane] = 0u; sh_cnt[lane] = 0u; }
+  if (lane < P.O) { sh_off[2 * lane] = P.di[lane]; sh_off[2 * lane + 1] = P.dj[lane]; }
   for (int i = lane; i < MN_X_MAXBLOCKS / 64; i += 64) l2[i] = 0ull;
   MN_X_LDS_SYNC();
   for (int g = 0; g < X.NG; g++) mn_x_group_refresh(l1, l2, g, lane);
@@ -708,7 +738,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     unsigned newp = 0;
     int newcap = 0;
     if (la + lb > capa) {
-      newcap = ((4 * (la + lb) + 63) / 64) * 64;
+      newcap = ((2 * (la + lb) + 31) / 32) * 32;    // (doubling: 86 arena entries per pixel at O = 10, tests/tools/exact_model.cpp)
       if (bump + (unsigned long long)newcap > Xc->arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
       newp = (unsigned)bump;
       bump += (unsigned long long)newcap;
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       int cnt = 0;
       for (int j0 = 0; j0 < la; j0 += 64) {
         const int j = j0 + lane;
-        unsigned e = (j < la) ? X.arena[(size_t)pa + j] : MN_X_INVALID;
+        const unsigned e = mn_x_entry(X.arena, pa, j, la, a, P.O, P.W, P.H, sh_off);
         bool live = e != MN_X_INVALID && e != rid;
         if (live) live = X.rec[e].key != MN_EMPTY;
         const u64 mk = __ballot(live);
@@ -757,7 +787,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     // ---- the absorbed object's records (:650-707), 64 per pass ----
     for (int j0 = 0; j0 < lb; j0 += 64) {
       const int j = j0 + lane;
-      const unsigned e = (j < lb) ? X.arena[(size_t)pb + j] : MN_X_INVALID;
+      const unsigned e = mn_x_entry(X.arena, pb, j, lb, b, P.O, P.W, P.H, sh_off);
       bool live = e != MN_X_INVALID && e != rid;
       u64 kt = MN_EMPTY;
       float St = 0.0f;
@@ -795,7 +825,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
           }
         key2 = mn_key(a, c3);
         unsigned b1, b2;
-        mn_x_buckets(key2, X.bmask, &b1, &b2);
+        mn_x_buckets(key2, X.nb, &b1, &b2);
         uint4 sl[8];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -865,7 +895,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
           cm &= cm - 1ull;
           if (lane == 0) sh_cnt[MN_XC_SLOW] += 1u;
           if (lane == l) {
-            nslot = mn_x_insert_slow(X.hs, X.rec, X.bmask, key2, e, St, (Xc->dbg & 1) != 0);
+            nslot = mn_x_insert_slow(X.hs, X.rec, X.nb, key2, e, St, (Xc->dbg & 1) != 0);
             XRec nr; nr.key = key2; nr.S = St; nr.slot = nslot;
             *reinterpret_cast<uint4*>(&X.rec[e]) = *reinterpret_cast<const uint4*>(&nr);
           }
@@ -991,11 +1021,11 @@ __global__ __launch_bounds__(256) void mn_x_check_slots(XState X) {
   if (i < X.NL) {
     const XRec R = X.rec[i];
     if (R.key != MN_EMPTY) {
-      if (R.slot == MN_X_INVALID || R.slot >= (X.bmask + 1u) * 4u) bad++;
+      if (R.slot == MN_X_INVALID || R.slot >= X.nb * 4u) bad++;
       else { const XSlot s = X.hs[R.slot]; if (s.key != R.key || s.rid != (unsigned)i || s.S != R.S) bad++; }
     }
   }
-  if (i < ((size_t)X.bmask + 1) * 4) {
+  if (i < (size_t)X.nb * 4) {
     const XSlot s = X.hs[i];
     if (s.key != MN_X_HEMPTY) {
       if (s.rid >= X.NL) bad++;

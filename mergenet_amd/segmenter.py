@@ -288,6 +288,9 @@ class HostContext:
         except Exception:
             pass
 
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mn_workspace_bytes(self.handle))
+
     def segment(self, class_probs: np.ndarray, same_probs: np.ndarray, offsets,
                 opts: Optional[MnOptions] = None, want_partition: bool = True):
         cp = np.ascontiguousarray(class_probs, dtype=np.float32)

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <set>
 #include <unordered_map>
 #include <vector>
@@ -50,6 +51,25 @@ struct Model {
   long long tied_conflicts = 0;
   long long max_depth = 0;
   int track = 0;
+  // ---- arena accounting (design aid): what the engine's adjacency arena would need under a policy ----
+  int cap0 = 64, growth = 4, round_to = 64, reuse = 0;
+  std::vector<int> acap, alen;                          // per object: capacity, entries in use (dead ones included)
+  long long bump = 0, reallocs = 0, moved = 0;
+  std::vector<std::vector<long long>> freelist;         // by size class (log2)
+  long long alloc_block(int cap) {
+    if (reuse) {
+      int c = 0; while ((1 << c) < cap) c++;
+      if ((int)freelist.size() > c && !freelist[c].empty()) { long long p = freelist[c].back(); freelist[c].pop_back(); return p; }
+    }
+    const long long p = bump; bump += cap; return p;
+  }
+  void free_block(int cap) {
+    if (!reuse) return;
+    int c = 0; while ((1 << c) < cap) c++;
+    if ((1 << c) != cap) return;                        // (only power-of-two blocks are recycled)
+    if ((int)freelist.size() <= c) freelist.resize(c + 1);
+    freelist[c].push_back(0);
+  }
 
   float score(int a, int b, float s, int* mc) const {
     float cdl = 0.0f;
@@ -99,6 +119,7 @@ struct Model {
     N = W * H;
     lp.resize((size_t)N * C); ocls.resize(N); osize.assign(N, 1); parent.resize(N); adj.resize(N);
     stamp.assign(N, 0);
+    acap.assign(N, cap0); alen.assign(N, 0); bump = (long long)N * cap0;
     for (int p = 0; p < N; p++) {
       float* l = &lp[(size_t)p * C];
       int best = 0;
@@ -120,6 +141,7 @@ struct Model {
         r1[r] = std::min(p, qx); r2[r] = std::max(p, qx);
         S[r] = same - diff;
         adj[p][qx] = r; adj[qx][p] = r;
+        alen[p]++; alen[qx]++;
         int mc;
         const float f = score(r1[r], r2[r], S[r], &mc);
         prio[r] = f;
@@ -161,6 +183,20 @@ struct Model {
       const float* lb = &lp[(size_t)b * C];
       for (int c = 0; c < C; c++) la[c] += lb[c];
       adj[a].erase(b); adj[b].erase(a);
+      {
+        // the engine: room for every record the survivor may adopt, checked before the walk
+        const int la = alen[a], lb = alen[b];
+        if (la + lb > acap[a]) {
+          int need = growth * (la + lb);
+          int nc = reuse ? 1 : 0;
+          if (reuse) { nc = round_to; while (nc < need) nc <<= 1; } else nc = ((need + round_to - 1) / round_to) * round_to;
+          alloc_block(nc);
+          free_block(acap[a]);
+          reallocs++; moved += (long long)adj[a].size();
+          acap[a] = nc; alen[a] = (int)adj[a].size();       // (dead entries are dropped on the way)
+        }
+      }
+      int adopted_n = 0;
       for (auto& kv : adj[b]) {
         const int c3 = kv.first, t = kv.second;
         touch(c3, ev);
@@ -181,10 +217,13 @@ struct Model {
           sibling_check(prio[t]);
           r1[t] = std::min(a, c3); r2[t] = std::max(a, c3);
           adj[a][c3] = t; adj[c3][a] = t;
+          adopted_n++;
         }
         int m2;
         store(tr, score(r1[tr], r2[tr], S[tr], &m2));
       }
+      alen[a] += adopted_n;
+      free_block(acap[b]);
       std::unordered_map<int, int>().swap(adj[b]);
       parent[b] = a;
     }
@@ -199,12 +238,17 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
                                const int* offs, float omf, float bias, int track, int* partition, int* obj_class,
                                double* stats) {
   Model m;
+  if (const char* e = getenv("XM_CAP0")) m.cap0 = atoi(e);
+  if (const char* e = getenv("XM_GROWTH")) m.growth = atoi(e);
+  if (const char* e = getenv("XM_ROUND")) m.round_to = atoi(e);
+  if (const char* e = getenv("XM_REUSE")) m.reuse = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   for (int p = 0; p < W * H; p++) { const int o = m.root(p); partition[p] = o; obj_class[p] = m.ocls[o]; }
   if (stats) {
     stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
     stats[3] = (double)m.tied_merges; stats[4] = (double)m.tied_conflicts; stats[5] = (double)m.max_depth;
+    stats[6] = (double)m.bump; stats[7] = (double)m.reallocs;
   }
   return 0;
 }

@@ -37,6 +37,7 @@ for name in gu.names("cseg_"):
         st["num_instances"], st["ms_merge"], st["proof"], st["certified"], st["tied_steps"], st.get("tied_conflicts", -1)), flush=True)
     if not ok:
         bad.append(name)
+    print("    workspace %.3f GB (%.0f B per pixel)" % (ctx.workspace_bytes() / 1e9, ctx.workspace_bytes() / (H * W)))
     ctx.close()
 print("mismatching:", bad)
 sys.exit(1 if bad else 0)
