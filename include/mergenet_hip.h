@@ -82,6 +82,7 @@ enum mn_proof {
                                     image in the reference's order                                                   */
 };
 #define MN_TIE_LIMIT_RECORDS 400000   /* MN_TIES_DEFAULT: largest image (initial records) redone in the reference's order */
+#define MN_TIE_LIMIT_BATCH_RECORDS 1400000   /* ... inside mn_segment_exact_batch, where the images are redone together (256x512 at O = 10) */
 
 typedef struct mn_options {
   float same_different_bias;   /* segment.h:246 */
@@ -249,8 +250,10 @@ int mn_sweep_time_device(mn_context* ctx, const float* const* d_class_pred, cons
  * sequential order gets throughput (the reference scales the same way, by processes: --num-jobs).  One
  * context per image (each holds its image's workspace, ~1.5 GB at 512x1024, ~6 GB at 1024x2048); arrays of
  * `count` device pointers (host arrays); d_partition may be NULL; stats: `count` entries or NULL.  The call
- * returns when all images are done.  Results are those of `count` separate MN_MODE_EXACT calls (an image the
- * tie policy sends to the reference-order loop -- opts->tie_order -- is then run on its own). */
+ * returns when all images are done.  Results are those of `count` separate MN_MODE_EXACT calls; the images the
+ * tie policy sends to the reference-order loop (opts->tie_order; stats.tied_conflicts > 0) are redone TOGETHER,
+ * one workgroup per image in one launch of that loop, and up to MN_TIE_LIMIT_BATCH_RECORDS initial records
+ * instead of MN_TIE_LIMIT_RECORDS (the loop is sequential: images in flight are its throughput). */
 int mn_segment_exact_batch(mn_context** ctxs, int count, const float* const* d_class_pred, int class_dim,
                            const float* const* d_adj_pred, int offset_dim, int img_width, int img_height,
                            int num_classes, const int* offset_list, int* const* d_mask,

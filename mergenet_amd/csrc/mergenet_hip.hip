@@ -160,6 +160,8 @@ struct mn_context {
     int n_pix; long long n_rec; int n_cls; long long arena_cap, heap_cap;
     int arena_per_pixel, heap_per_record;     // (doubled when a run fills them)
     long long* h_ctl;             // pinned
+    RoState* d_S;                 // device copies of a batch's states (first context of the batch)
+    int batch_cap;
   } rw;
   int tie_ref;                    // this attempt: MN_TIES_* as asked for
   int tie_used;                   // ... and what the last exact attempt ran in the end
@@ -216,9 +218,10 @@ static void r_free(mn_context* c) {
   if (c->rw.block) (void)hipFree(c->rw.block);
   if (c->rw.h_ctl) (void)hipHostFree(c->rw.h_ctl);
   c->bytes -= c->rw.bytes;
-  const int ap = c->rw.arena_per_pixel, hp = c->rw.heap_per_record;
+  const int ap = c->rw.arena_per_pixel, hp = c->rw.heap_per_record, bc = c->rw.batch_cap;
+  RoState* ds = c->rw.d_S;
   memset(&c->rw, 0, sizeof(c->rw));
-  c->rw.arena_per_pixel = ap; c->rw.heap_per_record = hp;
+  c->rw.arena_per_pixel = ap; c->rw.heap_per_record = hp; c->rw.d_S = ds; c->rw.batch_cap = bc;
 }
 
 template <typename T>
@@ -473,6 +476,7 @@ extern "C" void mn_destroy(mn_context* c) {
   r_free(c);
   if (c->xw.d_P) (void)hipFree(c->xw.d_P);
   if (c->xw.d_X) (void)hipFree(c->xw.d_X);
+  if (c->rw.d_S) (void)hipFree(c->rw.d_S);
   free_records(c);
   if (c->h_statblk) (void)hipHostFree(c->h_statblk);
   if (c->h_touch) (void)hipHostFree(c->h_touch);
@@ -1198,64 +1202,158 @@ static int r_ensure(mn_context* c, int N, int O, int C) {
   return MN_OK;
 }
 
-// The exact engine's set-up (class vectors, records with the reference's log-odds), then ONE lane runs the
+// The exact engine's set-up (class vectors, records with the reference's log-odds), then ONE wave per image runs the
 // reference's constructor loop and merge loop on its containers (mn_reforder.h); a run that fills the bucket
-// arena or the queue is repeated with twice as much.
-static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
+// arena or the queue is repeated with twice as much.  A batch of images is ONE launch of the loop with a
+// workgroup per image (the loop is sequential in the reference's own data structures: images in flight are its
+// throughput, as for the exact engine).
+// set-up of one image; returns 1 when the parallel map construction ran out of bucket arena (grown, try again)
+static int ro_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   if (P.variant != MN_VARIANT_CSEGMENT) return MN_ERR_ARGUMENT;
+  int rc = exact_setup(c, P, st);
+  if (rc != MN_OK) return rc;
+  rc = r_ensure(c, P.N, P.O, P.C);
+  if (rc != MN_OK) return rc;
+  mn_context::RWork& w = c->rw;
+  XState& X = c->xw.X;
+  w.S.lp = X.lp; w.S.parent = X.parent; w.S.omf = P.omf; w.S.bias = P.bias;
+  const RoState S = w.S;
+  hipLaunchKernelGGL(mn_ro_prepare_objects, dim3(grid_for((size_t)P.N, 256)), dim3(256), 0, st, P, X, S);
+  hipLaunchKernelGGL(mn_ro_prepare_records, dim3(grid_for((size_t)S.NL, 256)), dim3(256), 0, st, P, X, S);
+  // (ctl[7]: lanes of the parallel map construction that found the bucket arena full)
+  hipLaunchKernelGGL(mn_ro_build_maps, dim3(grid_for((size_t)P.N, 64)), dim3(64), 0, st, P, S,
+                     reinterpret_cast<int*>(S.ctl + 7));
+  MN_HIP(hipGetLastError());
+  MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 128, hipMemcpyDeviceToHost, st));
+  return MN_OK;
+}
+
+// The loop of a batch (contexts set up by ro_setup), relaunched while any image has used up its pop budget;
+// device copies of the images' states live in the first context given.  full[i]: MN_RO_ARENA_FULL / MN_RO_HEAP_FULL
+// for an image whose workspace was too small (it grows and the caller repeats that image).
+static int ro_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st, unsigned char* full) {
+  mn_context::RWork& w0 = cs[0]->rw;
+  if (w0.batch_cap < n) {
+    if (w0.d_S) (void)hipFree(w0.d_S);
+    w0.d_S = nullptr;
+    MN_HIP(hipMalloc(reinterpret_cast<void**>(&w0.d_S), (size_t)n * sizeof(RoState)));
+    w0.batch_cap = n;
+  }
+  RoState* hs = static_cast<RoState*>(malloc((size_t)n * sizeof(RoState)));
+  if (!hs) return MN_ERR_INTERNAL;
+  long long max_pops = 0;
+  for (int i = 0; i < n; i++) {
+    hs[i] = cs[i]->rw.S;
+    // every loop ends: the reference pops each queue entry once, and a record is pushed at most once per
+    // re-score; 64 pops per initial record is far beyond what it does (4-5)
+    const long long mp = 64LL * hs[i].NL + 65536;
+    if (mp > max_pops) max_pops = mp;
+  }
+  hipError_t e1 = hipMemcpyAsync(w0.d_S, hs, (size_t)n * sizeof(RoState), hipMemcpyHostToDevice, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  free(hs);
+  MN_HIP(e1); MN_HIP(e2);
   long long per_launch = 1LL << 20;                  // pops per launch (MN_X_BUDGET: tests of the relaunch)
   if (const char* e = getenv("MN_X_BUDGET")) { const long long v = atoll(e); if (v > 0) per_launch = v; }
-  for (int attempt = 0; attempt < 6; attempt++) {
-    int rc = exact_setup(c, P, st);
-    if (rc != MN_OK) return rc;
-    rc = r_ensure(c, P.N, P.O, P.C);
-    if (rc != MN_OK) return rc;
-    mn_context::RWork& w = c->rw;
-    XState& X = c->xw.X;
-    RoState S = w.S;
-    S.lp = X.lp; S.parent = X.parent; S.omf = P.omf; S.bias = P.bias;
-    hipLaunchKernelGGL(mn_ro_prepare_objects, dim3(grid_for((size_t)P.N, 256)), dim3(256), 0, st, P, X, S);
-    hipLaunchKernelGGL(mn_ro_prepare_records, dim3(grid_for((size_t)S.NL, 256)), dim3(256), 0, st, P, X, S);
-    // (ctl[7]: lanes of the parallel map construction that found the bucket arena full)
-    hipLaunchKernelGGL(mn_ro_build_maps, dim3(grid_for((size_t)P.N, 64)), dim3(64), 0, st, P, S,
-                       reinterpret_cast<int*>(S.ctl + 7));
+  for (long long it = 0; it < (1 << 20); it++) {
+    hipLaunchKernelGGL(mn_ro_loop, dim3((unsigned)n), dim3(64), 0, st, (const RoState*)w0.d_S, Ps[0].O, per_launch);
     MN_HIP(hipGetLastError());
-    MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 128, hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < n; i++)
+      MN_HIP(hipMemcpyAsync(cs[i]->rw.h_ctl, cs[i]->rw.S.ctl, 128, hipMemcpyDeviceToHost, st));
     MN_HIP(hipStreamSynchronize(st));
-    if (w.h_ctl[7] != 0) { w.arena_per_pixel *= 2; continue; }
-    // every lane-0 loop ends: the reference pops each queue entry once, and a record is pushed at most once per
-    // re-score; 64 pops per initial record is far beyond what it does (4-5)
-    const long long max_pops = 64LL * S.NL + 65536;
-    long long status = MN_RO_RUNNING;
-    for (long long it = 0; it < (1 << 20); it++) {
-      hipLaunchKernelGGL(mn_ro_loop, dim3(1), dim3(64), 0, st, S, P.O, per_launch);
-      MN_HIP(hipGetLastError());
-      MN_HIP(hipMemcpyAsync(w.h_ctl, S.ctl, 128, hipMemcpyDeviceToHost, st));
-      MN_HIP(hipStreamSynchronize(st));
-      status = w.h_ctl[0];
-      if (status != MN_RO_BUDGET) break;
-      if (w.h_ctl[3] > max_pops) { status = MN_RO_CORRUPT; break; }
+    bool again = false;
+    for (int i = 0; i < n; i++) {
+      const long long status = cs[i]->rw.h_ctl[0];
+      if (status == MN_RO_BUDGET) {
+        if (cs[i]->rw.h_ctl[3] > max_pops) {
+          fprintf(stderr, "mergenet_hip: reference-order loop exceeded %lld pops\n", max_pops);
+          return MN_ERR_INTERNAL;
+        }
+        again = true;
+      }
     }
+    if (!again) break;
+  }
+  for (int i = 0; i < n; i++) {
+    mn_context::RWork& w = cs[i]->rw;
+    const long long status = w.h_ctl[0];
     if (getenv("MN_TRACE_EXACT"))
       fprintf(stderr, "reference-order loop: status %lld pops %lld merges %lld bucket arena %lld of %lld largest queue %lld of %lld; "
               "seconds: constructor's loop %.2f, pops (and stores of fresh priorities) %.2f, merges %.2f\n",
               status, w.h_ctl[3], w.h_ctl[4], w.h_ctl[2], w.arena_cap, w.h_ctl[6], w.heap_cap,
               (double)w.h_ctl[8] * 1e-8, (double)w.h_ctl[9] * 1e-8, (double)w.h_ctl[10] * 1e-8);
-    if (status == MN_RO_ARENA_FULL) { w.arena_per_pixel *= 2; continue; }
-    if (status == MN_RO_HEAP_FULL) { w.heap_per_record *= 2; continue; }
+    if (status == MN_RO_ARENA_FULL || status == MN_RO_HEAP_FULL) { full[i] = (unsigned char)status; continue; }
     if (status != MN_RO_DONE) {
       fprintf(stderr, "mergenet_hip: reference-order loop stopped with status %lld after %lld pops\n", status, w.h_ctl[3]);
       return MN_ERR_INTERNAL;
     }
-    const size_t n = (size_t)S.NL > (size_t)P.N ? (size_t)S.NL : (size_t)P.N;
-    hipLaunchKernelGGL(mn_ro_finish, dim3(grid_for(n, 256)), dim3(256), 0, st, P, X, S);
-    MN_HIP(hipGetLastError());
-    XCtl* h = c->xw.h_ctl;
-    h->steps = w.h_ctl[3]; h->merges = w.h_ctl[4];
-    h->tied_steps = 0; h->tied_merges = 0;           // (ties are resolved as the reference resolves them)
-    return MN_OK;
   }
-  return MN_ERR_CAPACITY;
+  return MN_OK;
+}
+
+static int ro_finish(mn_context* c, const ImgParams& P, hipStream_t st) {
+  mn_context::RWork& w = c->rw;
+  const RoState S = w.S;
+  const size_t n = (size_t)S.NL > (size_t)P.N ? (size_t)S.NL : (size_t)P.N;
+  hipLaunchKernelGGL(mn_ro_finish, dim3(grid_for(n, 256)), dim3(256), 0, st, P, c->xw.X, S);
+  MN_HIP(hipGetLastError());
+  XCtl* h = c->xw.h_ctl;
+  h->steps = w.h_ctl[3]; h->merges = w.h_ctl[4];
+  h->tied_steps = 0; h->tied_merges = 0;           // (ties are resolved as the reference resolves them)
+  h->tied_conflicts = 0;
+  return MN_OK;
+}
+
+// set-up, loop and hand-over of a batch; an image whose workspace was too small is repeated with a larger one
+static int run_reforder_batch(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st) {
+  mn_context** sub = static_cast<mn_context**>(malloc((size_t)n * sizeof(mn_context*)));
+  ImgParams* subP = static_cast<ImgParams*>(malloc((size_t)n * sizeof(ImgParams)));
+  unsigned char* full = static_cast<unsigned char*>(malloc((size_t)n));
+  int rc = (sub && subP && full) ? MN_OK : MN_ERR_INTERNAL;
+  int m = n;
+  for (int i = 0; i < n && rc == MN_OK; i++) { sub[i] = cs[i]; subP[i] = Ps[i]; }
+  for (int attempt = 0; rc == MN_OK && m > 0; attempt++) {
+    if (attempt == 8) { rc = MN_ERR_CAPACITY; break; }
+    for (int i = 0; i < m && rc == MN_OK; i++) rc = ro_setup(sub[i], subP[i], st);
+    if (rc != MN_OK) break;
+    MN_HIP(hipStreamSynchronize(st));
+    memset(full, 0, (size_t)m);
+    int ready = 0;                 // images whose maps were built: they go through the loop now
+    mn_context** run = static_cast<mn_context**>(malloc((size_t)m * sizeof(mn_context*)));
+    ImgParams* runP = static_cast<ImgParams*>(malloc((size_t)m * sizeof(ImgParams)));
+    int* idx = static_cast<int*>(malloc((size_t)m * sizeof(int)));
+    if (!run || !runP || !idx) { free(run); free(runP); free(idx); rc = MN_ERR_INTERNAL; break; }
+    for (int i = 0; i < m; i++) {
+      if (sub[i]->rw.h_ctl[7] != 0) { full[i] = MN_RO_ARENA_FULL; continue; }
+      run[ready] = sub[i]; runP[ready] = subP[i]; idx[ready] = i; ready++;
+    }
+    if (ready > 0) {
+      unsigned char* f2 = static_cast<unsigned char*>(calloc((size_t)ready, 1));
+      rc = f2 ? ro_loop(run, ready, runP, st, f2) : MN_ERR_INTERNAL;
+      for (int j = 0; j < ready && rc == MN_OK; j++) {
+        if (f2[j]) full[idx[j]] = f2[j];
+        else rc = ro_finish(run[j], runP[j], st);
+      }
+      free(f2);
+    }
+    free(run); free(runP); free(idx);
+    if (rc != MN_OK) break;
+    int k = 0;
+    for (int i = 0; i < m; i++) {
+      if (!full[i]) continue;
+      mn_context::RWork& w = sub[i]->rw;
+      if (full[i] == MN_RO_ARENA_FULL) w.arena_per_pixel *= 2; else w.heap_per_record *= 2;
+      sub[k] = sub[i]; subP[k] = subP[i]; k++;
+    }
+    m = k;
+  }
+  free(sub); free(subP); free(full);
+  return rc;
+}
+
+static int run_reforder(mn_context* c, const ImgParams& P, hipStream_t st) {
+  mn_context* one[1] = {c};
+  return run_reforder_batch(one, 1, &P, st);
 }
 
 // Did the run leave anything to the engine's own rule among bit-equal priorities?  Tied pops whose choices touched
@@ -1297,6 +1395,8 @@ static int run_exact_engine(mn_context* c, const ImgParams& P, hipStream_t st) {
       c->xw.h_ctl->tied_conflicts = tc; c->xw.h_ctl->ttrack = tt;
     }
   } else {
+    // (set-up and loop have run as part of a batch; prerun == 2: the reference-order loop too)
+    if (c->xw.prerun == 2) c->tie_used = MN_TIES_REFERENCE;
     MN_HIP(hipEventRecord(c->ev[1], st));
     MN_HIP(hipEventRecord(c->ev[2], st));
   }
@@ -1982,24 +2082,51 @@ extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float*
   for (int i = 0; i < count; i++)
     fill_params(&Ps[i], d_class_pred[i], d_adj_pred[i], offset_dim, W, H, num_classes, offset_list, &o);
   rc = exact_run(ctxs, count, Ps, st);
-  free(Ps);
-  if (rc != MN_OK) { g_last_status = rc; return rc; }
-  // hand-over and output stage of every image (labels, mask, class table, certificate, log-likelihood)
-  long long tie_limit = MN_TIE_LIMIT_RECORDS;
+  if (rc != MN_OK) { free(Ps); g_last_status = rc; return rc; }
+  // The tie policy, as a single call applies it: images whose tied choices conflict (or all, with
+  // MN_TIES_REFERENCE) are redone in the reference's order among equals -- TOGETHER, one workgroup per image in one
+  // launch of that loop.  Inside a batch the loop's cost is shared, so the size limit is higher than for a single
+  // call (MN_TIE_LIMIT_BATCH_RECORDS).
+  long long tie_limit = MN_TIE_LIMIT_BATCH_RECORDS;
   if (const char* e = getenv("MN_TIE_LIMIT")) tie_limit = atoll(e);
+  const bool ref_possible = o.variant == MN_VARIANT_CSEGMENT;
+  int n_redo = 0;
+  mn_context** rc_ctx = static_cast<mn_context**>(malloc((size_t)count * sizeof(mn_context*)));
+  ImgParams* rc_P = static_cast<ImgParams*>(malloc((size_t)count * sizeof(ImgParams)));
+  struct Saved { long long ts, tm, tc; int tt; };
+  Saved* saved = static_cast<Saved*>(malloc((size_t)count * sizeof(Saved)));
+  unsigned char* redo = static_cast<unsigned char*>(calloc((size_t)count, 1));
+  if (!rc_ctx || !rc_P || !saved || !redo) rc = MN_ERR_INTERNAL;
+  for (int i = 0; i < count && rc == MN_OK; i++) {
+    const XCtl* h = ctxs[i]->xw.h_ctl;
+    redo[i] = ref_possible && (o.tie_order == MN_TIES_REFERENCE ||
+                               (o.tie_order == MN_TIES_DEFAULT && x_ties_unresolved(h) &&
+                                (long long)W * H * offset_dim <= tie_limit));
+    if (!redo[i]) continue;
+    saved[n_redo] = Saved{h->tied_steps, h->tied_merges, h->tied_conflicts, h->ttrack};
+    rc_ctx[n_redo] = ctxs[i]; rc_P[n_redo] = Ps[i]; n_redo++;
+  }
+  if (rc == MN_OK && n_redo > 0) {
+    rc = run_reforder_batch(rc_ctx, n_redo, rc_P, st);
+    for (int j = 0; j < n_redo && rc == MN_OK; j++) {
+      XCtl* h = rc_ctx[j]->xw.h_ctl;
+      if (o.tie_order != MN_TIES_REFERENCE) {          // (what the exact engine met)
+        h->tied_steps = saved[j].ts; h->tied_merges = saved[j].tm; h->tied_conflicts = saved[j].tc; h->ttrack = saved[j].tt;
+      }
+    }
+  }
+  free(Ps); free(rc_ctx); free(rc_P); free(saved);
+  if (rc != MN_OK) { free(redo); g_last_status = rc; return rc; }
+  // hand-over and output stage of every image (labels, mask, class table, certificate, log-likelihood)
   for (int i = 0; i < count; i++) {
-    // (an image the tie policy sends to the reference-order loop takes the single-image path from the start)
-    const bool ref_possible = o.variant == MN_VARIANT_CSEGMENT;
-    const bool redo = ref_possible && (o.tie_order == MN_TIES_REFERENCE ||
-                                       (o.tie_order == MN_TIES_DEFAULT && x_ties_unresolved(ctxs[i]->xw.h_ctl) &&
-                                        (long long)W * H * offset_dim <= tie_limit));
-    ctxs[i]->xw.prerun = redo ? 0 : 1;
+    ctxs[i]->xw.prerun = redo[i] ? 2 : 1;
     const int r = segment_attempt(ctxs[i], d_class_pred[i], class_dim, d_adj_pred[i], offset_dim, W, H, num_classes,
                                   offset_list, d_mask[i], d_object_class[i], d_partition ? d_partition[i] : nullptr,
                                   &o, stream, stats ? &stats[i] : nullptr, MN_MODE_EXACT, false);
     ctxs[i]->xw.prerun = 0;
     if (r != MN_OK && rc == MN_OK) rc = r;
   }
+  free(redo);
   g_last_status = rc;
   return rc;
 }

@@ -137,10 +137,13 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
   mn_ro_wave_pushup(S, hole, vp, vr, lane);              // ... and back up with the last entry's value
 }
 
-// ONE wave: lane 0 runs the maps and the records (mn_reforder.h), the wave the queue.  Comes back when `budget`
-// pops (4 x budget records of the constructor's loop) are used up: the state is in memory, the next launch goes on.
-__global__ __launch_bounds__(64) void mn_ro_loop(RoState S, int O, long long budget) {
+// ONE wave per image (block b runs image b of a batch: images are independent): lane 0 runs the maps and the
+// records (mn_reforder.h), the wave the queue.  Comes back when `budget` pops (4 x budget records of the
+// constructor's loop) are used up: the state is in memory, the next launch goes on; a block whose image has
+// finished -- or waits for a larger workspace -- returns at once.
+__global__ __launch_bounds__(64) void mn_ro_loop(const RoState* __restrict__ Ss, int O, long long budget) {
   __shared__ int s_nodes[66];                            // the records of a walk (64), their count, the next node
+  RoState S = Ss[blockIdx.x];
   const int lane = threadIdx.x;
   const long long st0 = S.ctl[0];
   if (st0 != MN_RO_RUNNING && st0 != MN_RO_BUDGET) return;

@@ -471,3 +471,30 @@ def test_a_batch_honours_the_tie_policy(oracle):
                                            g["mask"], g["object_class"]), st
     finally:
         batch.close()
+
+
+def test_a_batch_redoes_large_tied_images_together(oracle):
+    """Inside a batch the reference-order loop runs a workgroup per image in ONE launch, so the tie policy reaches
+    further than in a single call (MN_TIE_LIMIT_BATCH_RECORDS: 256x512 at ten offsets): the tie-decided 256x512
+    vector -- which a single default call leaves to the engine's own rule (proof 3, and NOT the reference's
+    partition) -- comes out as the reference's, beside two other 256x512 images redone in the same launch."""
+    import torch
+    names = TIE_DECIDED_LARGE + ["cseg_blur_256x512_r2", "cseg_crowd48_256x512_s6408"]
+    gs = [gu.load(n) for n in names]
+    g0 = gs[0]
+    H, W, C = g0["spec"]["H"], g0["spec"]["W"], g0["spec"]["C"]
+    sdb, omf, bias = g0["spec"]["opts"]
+    o = seg.default_options(same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias,
+                            mode=seg.MN_MODE_EXACT, clip_inputs=1)
+    cps = [torch.from_numpy(np.ascontiguousarray(g["class_probs"], dtype=np.float32)).cuda() for g in gs]
+    sps = [torch.from_numpy(np.ascontiguousarray(g["sameness_probs"], dtype=np.float32)).cuda() for g in gs]
+    batch = seg.ExactBatch(H, W, C, len(g0["offsets"]), len(gs))
+    try:
+        res = batch.segment(cps, sps, g0["offsets"], o)
+        for n, g, (mask, table, part, st) in zip(names, gs, res):
+            assert st["tied_conflicts"] > 0 and st["tie_order_used"] == seg.MN_TIES_REFERENCE, (n, st)
+            assert st["proof"] == seg.MN_PROOF_SEQUENTIAL
+            assert oracle.masks_equivalent(mask.cpu().numpy(), seg._class_list(table.cpu().numpy()),
+                                           g["mask"], g["object_class"]), (n, st)
+    finally:
+        batch.close()
