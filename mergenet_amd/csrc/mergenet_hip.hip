@@ -142,6 +142,7 @@ struct mn_context {
   struct XWork {
     XState X;
     size_t n_pix, n_rec, n_cls_floats, hcap, arena_cap, leaf_cap;   // capacities of what is allocated
+    void* block;                  // the ONE allocation all arrays live in
     size_t bytes;
     XCtl* h_ctl;                  // pinned
     int lds_ready;
@@ -203,9 +204,8 @@ static hipError_t dev_alloc(mn_context* c, T** p, size_t n) {
 // ---- exact engine: workspace ------------------------------------------------------------------------
 static void x_free(mn_context* c) {
   XState& X = c->xw.X;
-  void* dev[] = {X.rec, X.leaf, X.hs, X.obj, X.acap, X.lp, X.arena, X.overflow, X.l1g, X.ctl, X.mlog, X.ostamp, X.tstack};
-  for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
-    if (dev[i]) (void)hipFree(dev[i]);
+  if (c->xw.block) (void)hipFree(c->xw.block);     // (every array of the workspace lives in this ONE allocation)
+  if (X.mlog) (void)hipFree(X.mlog);
   if (c->xw.h_ctl) (void)hipHostFree(c->xw.h_ctl);
   c->bytes -= c->xw.bytes;
   const mn_context::XWork keep = c->xw;
@@ -224,14 +224,6 @@ static void r_free(mn_context* c) {
   c->rw.arena_per_pixel = ap; c->rw.heap_per_record = hp; c->rw.d_S = ds; c->rw.batch_cap = bc;
 }
 
-template <typename T>
-static hipError_t x_alloc(mn_context* c, T** p, size_t n) {
-  const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
-  c->xw.bytes += b;
-  c->bytes += b;
-  return hipMalloc(reinterpret_cast<void**>(p), b);
-}
-
 // Sizes the workspace for an image of N pixels, O offsets, C classes.  Per pixel (C = 9, O = 10):
 // records 20 B x O, pair table 32-64 B x O (load <= 0.5 at the start, falling: pairs only disappear), class
 // vectors 4 B x C, objects 20 B, adjacency arena 4 B x (64 + 11 O + 8) (150 words per pixel are used at O = 10, 230 at O = 16;
@@ -248,10 +240,10 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   if (w.arena_extra <= 0) {
     w.arena_extra = 10 * O + 8;                       // (measured use: 8.6 entries per pixel and offset at O = 10, doubling reallocation)
     if (const char* e = getenv("MN_X_ARENA_EXTRA")) { const int v = atoi(e); if (v > 0) w.arena_extra = v; }   // (tests)
-    w.table_permille = 550;
+    w.table_permille = 600;
     if (const char* e = getenv("MN_X_TABLE_PERMILLE")) { const int v = atoi(e); if (v >= 50 && v <= 950) w.table_permille = v; }   // (tests)
   }
-  // pair table: 4-slot buckets for a load of table_permille / 1000 at the start (pairs only disappear: it falls)
+  // pair table: 4-slot buckets for a load of table_permille / 1000 (0.6) at the start (pairs only disappear: it falls)
   const size_t nbuckets = (size_t)((double)NL * 1000.0 / (4.0 * (double)w.table_permille)) + 64;
   if (nbuckets * 4 >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   // (single pixels keep no stored array: the arena only holds what merges allocate)
@@ -262,18 +254,28 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
       w.arena_cap < arena_cap || w.leaf_cap < leaf_cap) {
     x_free(c);
     XState& X = w.X;
-    MN_HIP(x_alloc(c, &X.rec, NL));
-    MN_HIP(x_alloc(c, &X.leaf, leaf_cap));
-    MN_HIP(x_alloc(c, &X.hs, nbuckets * 4));
-    MN_HIP(x_alloc(c, &X.obj, (size_t)N));
-    MN_HIP(x_alloc(c, &X.acap, (size_t)N));
-    MN_HIP(x_alloc(c, &X.lp, (size_t)N * C + 64));
-    MN_HIP(x_alloc(c, &X.arena, arena_cap));
-    MN_HIP(x_alloc(c, &X.overflow, ovf_cap));
-    MN_HIP(x_alloc(c, &X.l1g, (size_t)MN_X_MAXBLOCKS));
-    MN_HIP(x_alloc(c, &X.ctl, 1));
-    MN_HIP(x_alloc(c, &X.ostamp, (size_t)N));
-    MN_HIP(x_alloc(c, &X.tstack, (size_t)MN_X_TSTACK));
+    // ONE allocation for the whole workspace, the arrays at 2 MB-aligned offsets (the loop walks them at random)
+    {
+      const size_t al = ((size_t)N * O > (1u << 20)) ? ((size_t)2 << 20) : 4096;
+      size_t off = 0;
+      auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + al - 1) / al * al; return o; };
+      const size_t o_hs = take(nbuckets * 4 * sizeof(XSlot)), o_rec = take(NL * sizeof(XRec)),
+                   o_arena = take(arena_cap * sizeof(unsigned)), o_leaf = take(leaf_cap * sizeof(unsigned)),
+                   o_lp = take(((size_t)N * C + 64) * sizeof(float)), o_obj = take((size_t)N * sizeof(XObj)),
+                   o_acap = take((size_t)N * sizeof(int)), o_ostamp = take((size_t)N * sizeof(unsigned)),
+                   o_ovf = take(ovf_cap * sizeof(unsigned)), o_l1g = take((size_t)MN_X_MAXBLOCKS * sizeof(u64)),
+                   o_tstack = take((size_t)MN_X_TSTACK * sizeof(u64)), o_ctl = take(sizeof(XCtl));
+      MN_HIP(hipMalloc(&w.block, off));
+      w.bytes = off;
+      c->bytes += off;
+      char* b = static_cast<char*>(w.block);
+      X.hs = reinterpret_cast<XSlot*>(b + o_hs); X.rec = reinterpret_cast<XRec*>(b + o_rec);
+      X.arena = reinterpret_cast<unsigned*>(b + o_arena); X.leaf = reinterpret_cast<unsigned*>(b + o_leaf);
+      X.lp = reinterpret_cast<float*>(b + o_lp); X.obj = reinterpret_cast<XObj*>(b + o_obj);
+      X.acap = reinterpret_cast<int*>(b + o_acap); X.ostamp = reinterpret_cast<unsigned*>(b + o_ostamp);
+      X.overflow = reinterpret_cast<unsigned*>(b + o_ovf); X.l1g = reinterpret_cast<u64*>(b + o_l1g);
+      X.tstack = reinterpret_cast<u64*>(b + o_tstack); X.ctl = reinterpret_cast<XCtl*>(b + o_ctl);
+    }
     MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), sizeof(XCtl)));
     w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = nbuckets; w.arena_cap = arena_cap;
     w.leaf_cap = leaf_cap;
@@ -979,7 +981,6 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   hipLaunchKernelGGL(mn_x_init_objects, dim3(grid_for(N, 256)), dim3(256), 0, st, P, X, c->cls0);
   MN_HIP(hipEventRecord(c->ev[1], st));
   hipLaunchKernelGGL(mn_x_init_records, dim3(grid_for((size_t)X.NL, 256)), dim3(256), 0, st, P, X);
-  hipLaunchKernelGGL(mn_x_place_overflow, dim3(1), dim3(64), 0, st, X);
   MN_HIP(hipEventRecord(c->ev[2], st));
   MN_HIP(hipGetLastError());
   return MN_OK;
@@ -1120,7 +1121,7 @@ static int exact_export(mn_context* c, const ImgParams& P, hipStream_t st) {
   if (getenv("MN_TRACE_EXACT"))
     fprintf(stderr, "exact engine: steps %lld merges %lld rescans %lld reallocs %lld folded %lld adopted %lld slow inserts %lld set-up overflow %d arena %llu of %llu\n",
             w.h_ctl->steps, w.h_ctl->merges, w.h_ctl->rescans, w.h_ctl->reallocs, w.h_ctl->folded,
-            w.h_ctl->adopted, w.h_ctl->slow_inserts, w.h_ctl->n_overflow, w.h_ctl->bump, X.arena_cap);
+            w.h_ctl->adopted, w.h_ctl->slow_inserts, abs(w.h_ctl->n_overflow), w.h_ctl->bump, X.arena_cap);
 #ifdef MN_X_STAMPS
   if (getenv("MN_TRACE_EXACT")) {
     static const char* nm[12] = {"loop", "pop", "record+scan", "objects+score", "restale", "merge-state", "realloc",

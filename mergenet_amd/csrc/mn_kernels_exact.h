@@ -63,7 +63,7 @@ enum { MN_X_RUNNING = 0, MN_X_DONE = 1, MN_X_BUDGET = 2, MN_X_ARENA_FULL = 3, MN
 
 struct XCtl {
   int status;                 // MN_X_*; < 0: mn_status error
-  int n_overflow;             // records the parallel set-up could not place in the pair table
+  int n_overflow;             // records the parallel set-up could not place in the pair table (negative: placed by the loop's kernel)
   long long steps, merges, rescans, reallocs, folded, adopted, slow_inserts;
   unsigned long long bump;    // next free arena entry
   long long stamps[16];       // -DMN_X_STAMPS (diagnostic build): cycles per phase of the loop
@@ -276,6 +276,36 @@ __device__ __noinline__ unsigned mn_x_insert_slow(XSlot* hs, XRec* rec, unsigned
     const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
     if (hs[s].key == MN_X_HEMPTY) { hs[s] = ns; return s; }
   }
+  // Two moves: an occupant v of my buckets goes to its other bucket after an occupant w of THAT bucket has gone to
+  // its own other bucket.  (With single moves only, one key in ~10^8 insertions found no room at a table load of
+  // 0.55 -- twice in eight 1024x2048 images -- and the whole run was repeated with a larger table.)
+  for (int t = 0; t < 8; t++) {
+    const unsigned s = (t < 4) ? (b1 * 4 + t) : (b2 * 4 + t - 4);
+    const XSlot v = hs[s];
+    if (v.key == MN_X_HEMPTY) continue;
+    unsigned v1, v2;
+    mn_x_buckets(v.key, nb, &v1, &v2);
+    const unsigned alt = ((s >> 2) == v1) ? v2 : v1;
+    if (alt == b1 || alt == b2) continue;
+    for (int q = 0; q < 4; q++) {
+      const unsigned s2 = alt * 4 + q;
+      const XSlot w = hs[s2];
+      if (w.key == MN_X_HEMPTY) continue;
+      unsigned w1, w2;
+      mn_x_buckets(w.key, nb, &w1, &w2);
+      const unsigned alt2 = (alt == w1) ? w2 : w1;
+      if (alt2 == b1 || alt2 == b2 || alt2 == alt) continue;
+      for (int q2 = 0; q2 < 4; q2++)
+        if (hs[alt2 * 4 + q2].key == MN_X_HEMPTY) {
+          hs[alt2 * 4 + q2] = w;
+          rec[w.rid].slot = alt2 * 4 + q2;
+          hs[s2] = v;
+          rec[v.rid].slot = s2;
+          hs[s] = ns;
+          return s;
+        }
+    }
+  }
   return MN_X_INVALID;
 }
 
@@ -355,20 +385,6 @@ __global__ __launch_bounds__(256) void mn_x_init_records(ImgParams P, XState X) 
   R.key = key; R.S = oml; R.slot = slot;
   X.rec[rid] = R;
   X.leaf[rid] = mn_x_word(pr);
-}
-
-// the few records both of whose buckets were full when the set-up kernel came by: one lane, one by one
-__global__ __launch_bounds__(64) void mn_x_place_overflow(XState X) {
-  if (threadIdx.x != 0) return;
-  const int n = X.ctl->n_overflow;
-  if (n > X.overflow_cap) { X.ctl->status = MN_X_HASH_FULL; return; }
-  for (int i = 0; i < n; i++) {
-    const unsigned rid = X.overflow[i];
-    const XRec R = X.rec[rid];
-    const unsigned s = mn_x_insert_slow(X.hs, X.rec, X.nb, R.key, rid, R.S);
-    if (s == MN_X_INVALID) { X.ctl->status = MN_X_HASH_FULL; return; }
-    X.rec[rid].slot = s;
-  }
 }
 
 // block maxima of the queue words
@@ -587,6 +603,29 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   }
   unsigned long long bump = X.ctl->bump;
   int status = X.ctl->status < 0 || X.ctl->status == MN_X_HASH_FULL ? X.ctl->status : MN_X_RUNNING;
+  {
+    // The records both of whose buckets were full when the parallel set-up came by: placed here, one by one, by a
+    // single lane that may move occupants to their other buckets.  Inside the loop's kernel because the images of
+    // a batch then do it side by side (as a kernel of its own it ran once per image, one after the other).
+    const int nov = X.ctl->n_overflow;
+    if (nov > Xc->overflow_cap) status = MN_X_HASH_FULL;
+    else if (nov > 0 && status == MN_X_RUNNING) {
+      int bad = 0;
+      if (lane == 0) {
+        const unsigned* ovf = Xc->overflow;
+        for (int i = 0; i < nov && !bad; i++) {
+          const unsigned orid = ovf[i];
+          const XRec R = X.rec[orid];
+          const unsigned sl = mn_x_insert_slow(X.hs, X.rec, X.nb, R.key, orid, R.S);
+          if (sl == MN_X_INVALID) bad = 1; else X.rec[orid].slot = sl;
+        }
+        X.ctl->n_overflow = -nov;               // (done; the count stays readable)
+      }
+      if (__shfl(bad, 0)) status = MN_X_HASH_FULL;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+
 #ifdef MN_X_STAMPS
   long long st_acc[16];
   for (int i = 0; i < 16; i++) st_acc[i] = 0;
