@@ -181,9 +181,9 @@ def default_mode_block(seg, pool_images, seeds, offs, device, max_batch):
     m.close()
     del mask, table
     torch.cuda.empty_cache()
-    # as many images as fit: a context that only serves the exact engine holds ~1.2 KB per pixel at C = 9, O = 10
+    # as many images as fit: a context that only serves the exact engine holds ~1.06 KB per pixel at C = 9, O = 10
     # (records, queue leaves, pair table, adjacency arena, object state) + its outputs
-    per_image = int(1250 * H * W + 2 * 4 * H * W)
+    per_image = int(1100 * H * W + 2 * 4 * H * W)
     free, _total = torch.cuda.mem_get_info(device)
     count = int(max(1, min(max_batch, (0.92 * free) // per_image)))
     batch_out = None

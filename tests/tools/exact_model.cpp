@@ -52,21 +52,25 @@ struct Model {
   long long max_depth = 0;
   int track = 0;
   // ---- arena accounting (design aid): what the engine's adjacency arena would need under a policy ----
-  int cap0 = 64, growth = 4, round_to = 64, reuse = 0;
+  int cap0 = 64, growth = 4, round_to = 64, reuse = 0, growth_pct = 0;
   std::vector<int> acap, alen;                          // per object: capacity, entries in use (dead ones included)
   long long bump = 0, reallocs = 0, moved = 0;
   std::vector<std::vector<long long>> freelist;         // by size class (log2)
+  int cls_of(int cap) const {
+    if (reuse == 2) return cap / round_to;              // exact sizes (multiples of round_to)
+    int c = 0; while ((1 << c) < cap) c++; return c;
+  }
   long long alloc_block(int cap) {
     if (reuse) {
-      int c = 0; while ((1 << c) < cap) c++;
+      const int c = cls_of(cap);
       if ((int)freelist.size() > c && !freelist[c].empty()) { long long p = freelist[c].back(); freelist[c].pop_back(); return p; }
     }
     const long long p = bump; bump += cap; return p;
   }
   void free_block(int cap) {
-    if (!reuse) return;
-    int c = 0; while ((1 << c) < cap) c++;
-    if ((1 << c) != cap) return;                        // (only power-of-two blocks are recycled)
+    if (!reuse || cap <= 0) return;
+    const int c = cls_of(cap);
+    if (reuse == 1 && (1 << c) != cap) return;          // (only power-of-two blocks are recycled)
     if ((int)freelist.size() <= c) freelist.resize(c + 1);
     freelist[c].push_back(0);
   }
@@ -187,9 +191,9 @@ struct Model {
         // the engine: room for every record the survivor may adopt, checked before the walk
         const int la = alen[a], lb = alen[b];
         if (la + lb > acap[a]) {
-          int need = growth * (la + lb);
+          int need = growth_pct ? (int)((long long)(la + lb) * growth_pct / 100) : growth * (la + lb);
           int nc = reuse ? 1 : 0;
-          if (reuse) { nc = round_to; while (nc < need) nc <<= 1; } else nc = ((need + round_to - 1) / round_to) * round_to;
+          if (reuse == 1) { nc = round_to; while (nc < need) nc <<= 1; } else nc = ((need + round_to - 1) / round_to) * round_to;
           alloc_block(nc);
           free_block(acap[a]);
           reallocs++; moved += (long long)adj[a].size();
@@ -242,6 +246,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_GROWTH")) m.growth = atoi(e);
   if (const char* e = getenv("XM_ROUND")) m.round_to = atoi(e);
   if (const char* e = getenv("XM_REUSE")) m.reuse = atoi(e);
+  if (const char* e = getenv("XM_GROWTH_PCT")) m.growth_pct = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   for (int p = 0; p < W * H; p++) { const int o = m.root(p); partition[p] = o; obj_class[p] = m.ocls[o]; }
