@@ -238,7 +238,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   const size_t NB = (NL + B - 1) / B;
   const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
   if (w.arena_extra <= 0) {
-    w.arena_extra = 10 * O + 8;                       // (measured use: 8.6 entries per pixel and offset at O = 10, doubling reallocation)
+    w.arena_extra = 8 * O + 8;                        // (measured use: 6.4 entries per pixel and offset at O = 10: doubling reallocation, exact-size free lists)
     if (const char* e = getenv("MN_X_ARENA_EXTRA")) { const int v = atoi(e); if (v > 0) w.arena_extra = v; }   // (tests)
     w.table_permille = 600;
     if (const char* e = getenv("MN_X_TABLE_PERMILLE")) { const int v = atoi(e); if (v >= 50 && v <= 950) w.table_permille = v; }   // (tests)
@@ -264,7 +264,8 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
                    o_lp = take(((size_t)N * C + 64) * sizeof(float)), o_obj = take((size_t)N * sizeof(XObj)),
                    o_acap = take((size_t)N * sizeof(int)), o_ostamp = take((size_t)N * sizeof(unsigned)),
                    o_ovf = take(ovf_cap * sizeof(unsigned)), o_l1g = take((size_t)MN_X_MAXBLOCKS * sizeof(u64)),
-                   o_tstack = take((size_t)MN_X_TSTACK * sizeof(u64)), o_ctl = take(sizeof(XCtl));
+                   o_tstack = take((size_t)MN_X_TSTACK * sizeof(u64)), o_free = take((size_t)MN_X_FREE_CLASSES * sizeof(unsigned)),
+                   o_ctl = take(sizeof(XCtl));
       MN_HIP(hipMalloc(&w.block, off));
       w.bytes = off;
       c->bytes += off;
@@ -275,6 +276,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
       X.acap = reinterpret_cast<int*>(b + o_acap); X.ostamp = reinterpret_cast<unsigned*>(b + o_ostamp);
       X.overflow = reinterpret_cast<unsigned*>(b + o_ovf); X.l1g = reinterpret_cast<u64*>(b + o_l1g);
       X.tstack = reinterpret_cast<u64*>(b + o_tstack); X.ctl = reinterpret_cast<XCtl*>(b + o_ctl);
+      X.freeheads = reinterpret_cast<unsigned*>(b + o_free);
     }
     MN_HIP(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctl), sizeof(XCtl)));
     w.n_pix = N; w.n_rec = NL; w.n_cls_floats = (size_t)N * C; w.hcap = nbuckets; w.arena_cap = arena_cap;
@@ -974,6 +976,7 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   MN_HIP(hipMemsetAsync(X.hs, 0xFF, (size_t)X.nb * 4 * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.leaf, 0, (((size_t)X.NB << X.Blog) + 1024) * sizeof(unsigned), st));
   MN_HIP(hipMemsetAsync(X.ostamp, 0, N * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.freeheads, 0xFF, MN_X_FREE_CLASSES * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
   w.h_ctl->ttrack = getenv("MN_X_NO_TIE_TRACKING") ? 0 : 1;          // (timing comparisons)
   w.h_ctl->bump = 0ull;

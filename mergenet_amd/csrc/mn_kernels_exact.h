@@ -51,7 +51,9 @@
 #define MN_X_LDS_OFF (MN_X_LDS_TIE + 32)          /* [2 * MN_MAX_OFFSETS] ints */
 #define MN_X_LDS_CTAB (MN_X_LDS_OFF + 2 * MN_MAX_OFFSETS * 4)
 #define MN_X_LDS_STK (MN_X_LDS_CTAB + 2048 * 4)
-#define MN_X_LDS_L2 (MN_X_LDS_STK + MN_X_TSTACK * 8)
+#define MN_X_LDS_FREE (MN_X_LDS_STK + MN_X_TSTACK * 8)   /* [MN_X_FREE_CLASSES] heads of the arena's free lists */
+#define MN_X_FREE_CLASSES 256
+#define MN_X_LDS_L2 (MN_X_LDS_FREE + MN_X_FREE_CLASSES * 4)
 #define MN_X_LDS_L1 (MN_X_LDS_L2 + (MN_X_MAXBLOCKS / 64) * 8)
 #define MN_X_LDS_BYTES(nbpad) ((size_t)MN_X_LDS_L1 + (size_t)(nbpad) * 8)
 // sh_cnt slots
@@ -110,6 +112,7 @@ struct XState {
   int* parent;                // [N] absorbed -> survivor (the context's union forest)
   unsigned* arena;
   unsigned long long arena_cap;
+  unsigned* freeheads;        // [MN_X_FREE_CLASSES] the arena's free lists between launches (heads; a free block's first word links on)
   unsigned* overflow;         // record ids the set-up kernel could not place (both buckets full)
   int overflow_cap;
   u64* l1g;                   // block maxima in HBM (built by mn_x_build_l1, loaded into LDS)
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   int* sh_off = reinterpret_cast<int*>(x_smem + MN_X_LDS_OFF);                    // [2 * O] offsets (d_row, d_col): implicit adjacency
   unsigned* sh_ctab = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_CTAB);        // [2048] same-slot check of a pass's inserts
   u64* sh_stk = reinterpret_cast<u64*>(x_smem + MN_X_LDS_STK);                    // [MN_X_TSTACK] nesting stack (ties)
+  unsigned* sh_free = reinterpret_cast<unsigned*>(x_smem + MN_X_LDS_FREE);        // [256] first free arena block of 32 * c entries (MN_X_INVALID: none)
   u64* l2 = reinterpret_cast<u64*>(x_smem + MN_X_LDS_L2);                         // [MN_X_MAXBLOCKS / 64] group maxima
   u64* l1 = reinterpret_cast<u64*>(x_smem + MN_X_LDS_L1);                         // [NBpad] block maxima
   const int lane = threadIdx.x;
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   for (int i = lane; i < Xc->NBpad; i += 64) l1[i] = (i < Xc->NB) ? Xc->l1g[i] : 0ull;
   if (lane < 8) { sh_gmask[lane] = 0u; sh_cnt[lane] = 0u; }
   if (lane < P.O) { sh_off[2 * lane] = P.di[lane]; sh_off[2 * lane + 1] = P.dj[lane]; }
+  for (int i = lane; i < MN_X_FREE_CLASSES; i += 64) sh_free[i] = Xc->freeheads[i];
   for (int i = lane; i < MN_X_MAXBLOCKS / 64; i += 64) l2[i] = 0ull;
   MN_X_LDS_SYNC();
   for (int g = 0; g < X.NG; g++) mn_x_group_refresh(l1, l2, g, lane);
@@ -773,14 +778,27 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     int capa = swap ? capy : capx;
     // room for the records the survivor may adopt; checked before anything is changed, so that a
     // full arena leaves a consistent state behind
-    bool moved = false;
-    unsigned newp = 0;
+    // Blocks of 32 * c entries (c < 256) are recycled through exact-size free lists (heads in LDS, a free
+    // block's first word links to the next): the array an absorbed object leaves behind and the one a survivor
+    // moves out of serve the next object that reaches that size (64 instead of 86 arena entries per pixel at
+    // O = 10, tests/tools/exact_model.cpp).
+    bool moved = false, reused = false;
+    unsigned newp = 0, free_next = MN_X_INVALID;
     int newcap = 0;
+    const unsigned pa_old = pa;
+    const int capa_old = capa;
     if (la + lb > capa) {
-      newcap = ((2 * (la + lb) + 31) / 32) * 32;    // (doubling: 86 arena entries per pixel at O = 10, tests/tools/exact_model.cpp)
-      if (bump + (unsigned long long)newcap > Xc->arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
-      newp = (unsigned)bump;
-      bump += (unsigned long long)newcap;
+      newcap = ((2 * (la + lb) + 31) / 32) * 32;    // (doubling)
+      const unsigned head = (newcap >> 5) < MN_X_FREE_CLASSES ? sh_free[newcap >> 5] : MN_X_INVALID;
+      if (head != MN_X_INVALID) {
+        newp = head;
+        free_next = X.arena[newp];                   // (read before the move overwrites it; used at the end of the merge)
+        reused = true;
+      } else {
+        if (bump + (unsigned long long)newcap > Xc->arena_cap) { status = MN_X_ARENA_FULL; steps--; break; }
+        newp = (unsigned)bump;
+        bump += (unsigned long long)newcap;
+      }
       moved = true;
     }
     if (Xc->mlog_cap > 0 && lane == 0) {
@@ -1008,7 +1026,19 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     if (lane == 0) {
       XObj o; o.size = na; o.cls = mc; o.aptr = pa; o.alen = la;
       X.obj[a] = o;
+      // the arena's free lists: the block taken leaves its list, then the blocks this merge vacated join theirs
+      if (reused) sh_free[newcap >> 5] = free_next;
+      if (moved && pa_old != MN_X_IMPLICIT && capa_old >= 32 && (capa_old >> 5) < MN_X_FREE_CLASSES && (capa_old & 31) == 0) {
+        X.arena[pa_old] = sh_free[capa_old >> 5];
+        sh_free[capa_old >> 5] = pa_old;
+      }
+      const int capb = swap ? capx : capy;
+      if (pb != MN_X_IMPLICIT && capb >= 32 && (capb >> 5) < MN_X_FREE_CLASSES && (capb & 31) == 0) {
+        X.arena[pb] = sh_free[capb >> 5];
+        sh_free[capb >> 5] = pb;
+      }
     }
+    MN_X_LDS_SYNC();
     MN_X_MEM_SYNC();
     // ---- re-read the blocks whose maximum was lowered or removed, then their groups ----
     for (int wd = 0; wd < 8; wd++) {
@@ -1036,6 +1066,7 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
   }
 
   for (int i = lane; i < sh_tie[MN_XT_DEPTH]; i += 64) Xc->tstack[i] = sh_stk[i];
+  for (int i = lane; i < MN_X_FREE_CLASSES; i += 64) Xc->freeheads[i] = sh_free[i];
   if (lane == 0) {
     XCtl* c = X.ctl;
 #ifdef MN_X_STAMPS

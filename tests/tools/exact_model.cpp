@@ -40,6 +40,7 @@ struct Model {
   std::vector<float> S, prio;                         // log-odds sum, stored priority (NaN-free; < 0: not queued)
   std::set<Key> q;
   long long steps = 0, merges = 0, tied_steps = 0, tied_merges = 0;
+  long long repop_merges = 0, refresh_then_other_refresh = 0, refresh_then_other_merge = 0; int last_refreshed = -1;
   // ---- tie-conflict criterion ----
   // Events form a forest by nesting: event j hangs under the last earlier event i with word(i) <= word(j)
   // such that everything between them is above word(i) (the suffix minima of the popped priorities).
@@ -175,7 +176,9 @@ struct Model {
       int mc;
       const float f = score(x, y, S[r], &mc);
       touch(x, ev); touch(y, ev);
-      if (f != top.p) { store(r, f); continue; }
+      if (f != top.p) { store(r, f); last_refreshed = r; continue; }
+      if (last_refreshed == r) repop_merges++;
+      last_refreshed = -1;
       // merge
       int a = x, b = y;
       if (osize[a] < osize[b]) std::swap(a, b);
@@ -253,7 +256,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (stats) {
     stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
     stats[3] = (double)m.tied_merges; stats[4] = (double)m.tied_conflicts; stats[5] = (double)m.max_depth;
-    stats[6] = (double)m.bump; stats[7] = (double)m.reallocs;
+    stats[6] = (double)m.bump; stats[7] = (double)m.reallocs; stats[8] = (double)m.repop_merges;
   }
   return 0;
 }

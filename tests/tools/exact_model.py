@@ -31,12 +31,12 @@ def run(class_probs, sameness_probs, offsets, omf, bias, clip=True, track=True):
     offs = np.ascontiguousarray(np.asarray(offsets, np.int32).reshape(-1))
     part = np.zeros((H, W), np.int32)
     ocls = np.zeros((H, W), np.int32)
-    stats = np.zeros(8, np.float64)
+    stats = np.zeros(12, np.float64)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int)
     lib.exact_model_run.restype = ctypes.c_int
     lib.exact_model_run(cp.ctypes.data_as(fp), sp.ctypes.data_as(fp), C, O, W, H, offs.ctypes.data_as(ip),
                         ctypes.c_float(omf), ctypes.c_float(bias), int(track), part.ctypes.data_as(ip),
                         ocls.ctypes.data_as(ip), stats.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
-    names = ("steps", "merges", "tied_steps", "tied_merges", "tied_conflicts", "max_depth", "arena_entries", "reallocs")
+    names = ("steps", "merges", "tied_steps", "tied_merges", "tied_conflicts", "max_depth", "arena_entries", "reallocs", "repop_merges")
     return part, ocls, {k: int(v) for k, v in zip(names, stats)}
