@@ -152,6 +152,7 @@ struct mn_context {
     int batch_cap;
     int arena_extra;              // arena words per pixel beyond the initial arrays (doubled when a run fills it)
     int table_permille;           // pair table: load at the start, in thousandths (lowered when a run fills the table)
+    int max_blocks;               // most queue blocks (0 = MN_X_MAXBLOCKS); smaller for the contexts of a large batch
   } xw;
   // the reference-order loop (mn_options.tie_order = MN_TIES_REFERENCE, mn_kernels_reforder.h)
   struct RWork {
@@ -211,7 +212,7 @@ static void x_free(mn_context* c) {
   const mn_context::XWork keep = c->xw;
   memset(&c->xw, 0, sizeof(c->xw));
   c->xw.d_P = keep.d_P; c->xw.d_X = keep.d_X; c->xw.batch_cap = keep.batch_cap;
-  c->xw.arena_extra = keep.arena_extra; c->xw.table_permille = keep.table_permille;
+  c->xw.arena_extra = keep.arena_extra; c->xw.table_permille = keep.table_permille; c->xw.max_blocks = keep.max_blocks;
 }
 
 static void r_free(mn_context* c) {
@@ -234,7 +235,11 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
   const size_t NL = (size_t)N * O;
   if (NL >= 0xFFFFFFF0ull) return MN_ERR_CAPACITY;
   size_t B = 256;
-  while ((NL + B - 1) / B > MN_X_MAXBLOCKS) B <<= 1;
+  // blocks of the queue: at most 16 K (128 KB of LDS: one image per compute unit); a context that is one of MORE
+  // images than the chip has compute units (xw.max_blocks, set by mn_segment_exact_batch) takes at most 6 K
+  // (72 KB with the rest of the loop's LDS: two images per compute unit, at the price of longer block scans)
+  const size_t max_blocks = w.max_blocks > 0 ? (size_t)w.max_blocks : (size_t)MN_X_MAXBLOCKS;
+  while ((NL + B - 1) / B > max_blocks) B <<= 1;
   const size_t NB = (NL + B - 1) / B;
   const size_t leaf_cap = NB * B + 1024;             // (a round of the block scan may read past a short block)
   if (w.arena_extra <= 0) {
@@ -2085,7 +2090,16 @@ extern "C" int mn_segment_exact_batch(mn_context** ctxs, int count, const float*
   int rc = MN_OK;
   for (int i = 0; i < count; i++)
     fill_params(&Ps[i], d_class_pred[i], d_adj_pred[i], offset_dim, W, H, num_classes, offset_list, &o);
+  {
+    // more images than compute units: two workgroups per unit if each keeps its LDS under half of it
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctxs[0]->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    for (int i = 0; i < count; i++) ctxs[i]->xw.max_blocks = count > ncu ? 6144 : 0;
+  }
   rc = exact_run(ctxs, count, Ps, st);
+  for (int i = 0; i < count; i++) ctxs[i]->xw.max_blocks = 0;
   if (rc != MN_OK) { free(Ps); g_last_status = rc; return rc; }
   // The tie policy, as a single call applies it: images whose tied choices conflict (or all, with
   // MN_TIES_REFERENCE) are redone in the reference's order among equals -- TOGETHER, one workgroup per image in one

@@ -498,3 +498,29 @@ def test_a_batch_redoes_large_tied_images_together(oracle):
                                            g["mask"], g["object_class"]), (n, st)
     finally:
         batch.close()
+
+
+def test_a_batch_with_more_images_than_compute_units():
+    """More images than the chip has compute units: mn_segment_exact_batch then gives every context at most 6 K queue
+    blocks (instead of 16 K), so that two workgroups share a unit's LDS -- the blocks are twice as long at this
+    size (320x640: 2 M records), the results must not change: every image equals the single call of its inputs."""
+    import torch
+    H, W, C = 320, 640, 9
+    offs = synth.generate_offsets(40, 10)
+    ims = [synth.synth_v1(H, W, C, offs, 1000 + i) for i in range(2)]
+    cps = [torch.from_numpy(im.class_probs).cuda() for im in ims]
+    sps = [torch.from_numpy(im.sameness_probs).cuda() for im in ims]
+    o = seg.default_options(merge_logprob_bias=0.03, mode=seg.MN_MODE_EXACT, clip_inputs=1, tie_order=seg.MN_TIES_LOWEST_ID)
+    one = seg.Merger(H, W, C, len(offs))
+    ref = [one.segment(cps[i], sps[i], offs, o, want_partition=True) for i in range(2)]
+    one.close()
+    n = torch.cuda.get_device_properties(0).multi_processor_count + 8
+    batch = seg.ExactBatch(H, W, C, len(offs), n)
+    try:
+        res = batch.segment([cps[i % 2] for i in range(n)], [sps[i % 2] for i in range(n)], offs, o, want_partition=True)
+        for i, (mask, table, part, st) in enumerate(res):
+            r = ref[i % 2]
+            assert torch.equal(mask, r[0]) and torch.equal(part, r[2]), i
+            assert (st["finisher_steps"], st["merges"], st["tied_steps"]) == (r[3]["finisher_steps"], r[3]["merges"], r[3]["tied_steps"]), i
+    finally:
+        batch.close()
