@@ -178,12 +178,12 @@ def default_mode_block(seg, pool_images, seeds, offs, device, max_batch):
               "equals_reference": equal(mask, table, st, goldens[0]),
               "how": "one mn_segment_device call with mn_default_options (AUTO): speculative attempt, certificate "
                      "fails, exact engine"}
+    # as many images as fit: a context that only serves the exact engine holds what this one holds minus the fast
+    # path's own arrays (fixed-point class sums, best-record slots, edge masks: 8 C + 28 B per pixel), + its outputs
+    per_image = int(1.03 * (m.workspace_bytes() - (8 * C + 28) * H * W) + 2 * 4 * H * W)
     m.close()
     del mask, table
     torch.cuda.empty_cache()
-    # as many images as fit: a context that only serves the exact engine holds ~1.06 KB per pixel at C = 9, O = 10
-    # (records, queue leaves, pair table, adjacency arena, object state) + its outputs
-    per_image = int(1100 * H * W + 2 * 4 * H * W)
     free, _total = torch.cuda.mem_get_info(device)
     count = int(max(1, min(max_batch, (0.92 * free) // per_image)))
     batch_out = None
@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine samples at smaller sizes")
     ap.add_argument("--no-default-mode", action="store_true",
                     help="skip the default-mode (proven path) measurement at 1024x2048: one image + one batch")
-    ap.add_argument("--default-batch", type=int, default=128,
+    ap.add_argument("--default-batch", type=int, default=160,
                     help="most images in the default-mode batch launch (fewer if they do not fit in memory)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (default), 2 rounds, 3 components")
     ap.add_argument("--no-kernel-events", action="store_true",

@@ -1270,6 +1270,8 @@ static int ro_loop(mn_context** cs, int n, const ImgParams* Ps, hipStream_t st, 
     for (int i = 0; i < n; i++)
       MN_HIP(hipMemcpyAsync(cs[i]->rw.h_ctl, cs[i]->rw.S.ctl, 128, hipMemcpyDeviceToHost, st));
     MN_HIP(hipStreamSynchronize(st));
+    if ((it & 31) == 31 && getenv("MN_TRACE_EXACT"))     // (a 1024x2048 image takes ~100 launches: a sign of life)
+      fprintf(stderr, "reference-order loop: launch %lld, image 0 at %lld pops\n", it + 1, cs[0]->rw.h_ctl[3]);
     bool again = false;
     for (int i = 0; i < n; i++) {
       const long long status = cs[i]->rw.h_ctl[0];
