@@ -14,14 +14,21 @@ the merges of the following steps, all of them complete inside the timed region)
 through POOL different images (636 MB of maps, more than the 256 MiB Infinity Cache), so a step
 reads its maps from HBM and not from a cache warmed by the previous step.
 
-Rank 0 prints ONE JSON line.  `value` = pixels merged by all ranks / wall time of the K timed
-steps (max over ranks), in Mpixel/s, on the library's SPECULATIVE fast path (mode AUTO with
-require_proof = -1: the component contraction when the maps are sign-separable, else the general rounds
--- `mode_used` says which ran).  On these images the fast path's answer is not certified (the 0.03 bias
-lets the background swallow small instances in a second phase whose order matters), so its equality with
-the reference is MEASURED on every image of the pool in every run (`id_match`, against the reference's
-own outputs) instead of proven; the library's default AUTO would redo such an image in the exact engine
-(`exact_engine`: the reference's sequential order on the GPU, timed here on a bounded sample).  `roofline` prices the slowest streaming kernel of the timed path with HIP events taken on
+Rank 0 prints ONE JSON line with BOTH paths on the same images:
+
+* `value` = pixels merged by all ranks / wall time of the K timed steps (max over ranks), in Mpixel/s, on the
+  library's SPECULATIVE fast path (mode AUTO with require_proof = -1: the component contraction when the maps are
+  sign-separable, else the general rounds -- `mode_used` says which ran).  On these images the fast path's answer
+  is not certified (the 0.03 bias lets the background swallow small instances in a second phase whose order
+  matters), so its equality with the reference is MEASURED on every image of the pool in every run (`id_match`,
+  against the reference's own outputs) instead of proven;
+* `value_proven_path` / `default_mode` = the library's DEFAULT behaviour on the same pool, outside the timed region:
+  one image through mn_default_options (AUTO: the speculative attempt fails its certificate, the exact engine --
+  the reference's sequential order on the GPU -- redoes the image) and ONE mn_segment_exact_batch launch of as many
+  1024x2048 images as fit the GPU's memory (a wavefront per image), every result compared with the reference's;
+  `exact_engine` holds single images at smaller sizes.
+
+`roofline` prices the slowest streaming kernel of the timed path with HIP events taken on
 the launch stream inside the library (algorithmic bytes: 4 B per plane value, SURVEY.md section
 8d: C class planes or O sameness planes per pass); `passes` lists every streaming pass of the
 step the same way, and `scoring_pass_general_path` is the class pass + edge pass of the general

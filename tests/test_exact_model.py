@@ -1,0 +1,48 @@
+"""tests/tools/exact_model.cpp -- the CPU model of the exact engine's semantics (the reference's lazy greedy with ties
+going to the lowest record id) and of its tie-conflict criterion -- against vectors taken from the reference
+(utils/csegment/segment.cc:539-727).  CPU only.  The GPU suite then compares the engine with this model
+(tests/test_gpu_exact.py::test_tie_conflict_verdict_equals_the_cpu_models)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from mergenet_amd import labels
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+import exact_model  # noqa: E402
+
+
+def _run(name):
+    g = gu.load(name)
+    sdb, omf, bias = g["spec"]["opts"]
+    assert sdb == 0.0
+    part, ocls, st = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias)
+    # the reference's mask: label 0 for class-0 objects, one label per other object (segment.cc:491-517)
+    mask = np.where(ocls == 0, 0, part + 1).astype(np.int64)
+    _, inv = np.unique(mask, return_inverse=True)
+    mask = inv.reshape(mask.shape)
+    if (ocls == 0).sum() == 0:
+        mask = mask + 1
+    classes = [int(ocls.reshape(-1)[np.argmax(mask.reshape(-1) == k)]) for k in range(1, int(mask.max()) + 1)]
+    return g, mask, classes, st
+
+
+@pytest.mark.parametrize("name", ["cseg_adv_32x32_o0", "cseg_adv_48x48_o0", "cseg_adv_48x48_o1", "cseg_adv_64x64_o1",
+                                  "cseg_blur_64x128_r2_s8001"])
+def test_no_tie_conflict_means_the_references_partition(name):
+    """Vectors with no tied pop, or with tied pops that the criterion calls harmless (cseg_blur_64x128_r2_s8001 has
+    86): the model -- whose order among equals is NOT the reference's -- must reproduce the reference's result."""
+    g, mask, classes, st = _run(name)
+    assert st["tied_conflicts"] == 0, st
+    assert labels.masks_equivalent(mask, classes, g["mask"], g["object_class"]), st
+
+
+def test_a_tie_decided_vector_is_reported_as_conflicting():
+    """cseg_blur4_128x256_s5100: the lowest-id rule ends elsewhere than the reference (115 199 pops against the
+    oracle's 115 297) -- and the criterion must have said so."""
+    g, mask, classes, st = _run("cseg_blur4_128x256_s5100")
+    assert st["steps"] == 115199 and st["tied_steps"] > 0 and st["tied_conflicts"] > 0, st
+    assert not labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])
