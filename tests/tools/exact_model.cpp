@@ -52,6 +52,33 @@ struct Model {
   long long tied_conflicts = 0;
   long long max_depth = 0;
   int track = 0;
+  // ---- how much could run side by side?  (design aid: XM_PARALLEL=1)  A ROOT is a pop at a new minimum of the popped
+  // priorities (stack depth 1); its super-event is everything popped until the next root.  Consecutive super-events
+  // with pairwise disjoint footprints (objects touched) commute: they could run on different waves. ----
+  int parallel_study = 0;
+  long long n_roots = 0, cur_root_events = 0, max_root_events = 0;
+  std::vector<int> cur_fp;                                 // objects touched by the current super-event
+  std::vector<long long> batch_mark;                       // per object: id of the batch that last claimed it
+  long long batch_id = 1, batch_len = 0, n_batches = 0, sum_batch_events = 0, cur_batch_events = 0;
+  std::vector<long long> batch_hist = std::vector<long long>(16, 0);   // batch length (super-events), log2 buckets
+  std::vector<std::vector<int>> all_fp;                    // every super-event's footprint, in order (window study)
+  void close_super_event() {
+    if (cur_root_events == 0) return;
+    std::sort(cur_fp.begin(), cur_fp.end());
+    cur_fp.erase(std::unique(cur_fp.begin(), cur_fp.end()), cur_fp.end());
+    bool clash = false;
+    for (int o : cur_fp) if (batch_mark[o] == batch_id) { clash = true; break; }
+    if (clash) {
+      int b = 0; while ((1LL << (b + 1)) <= batch_len && b < 15) b++;
+      batch_hist[b]++; n_batches++;
+      batch_id++; batch_len = 0;
+    }
+    for (int o : cur_fp) batch_mark[o] = batch_id;
+    batch_len++;
+    if (parallel_study >= 2) all_fp.push_back(cur_fp);
+    if (cur_root_events > max_root_events) max_root_events = cur_root_events;
+    cur_fp.clear(); cur_root_events = 0;
+  }
   // ---- arena accounting (design aid): what the engine's adjacency arena would need under a policy ----
   int cap0 = 64, growth = 4, round_to = 64, reuse = 0, growth_pct = 0;
   std::vector<int> acap, alen;                          // per object: capacity, entries in use (dead ones included)
@@ -124,6 +151,7 @@ struct Model {
     N = W * H;
     lp.resize((size_t)N * C); ocls.resize(N); osize.assign(N, 1); parent.resize(N); adj.resize(N);
     stamp.assign(N, 0);
+    if (parallel_study) batch_mark.assign(N, 0);
     acap.assign(N, cap0); alen.assign(N, 0); bump = (long long)N * cap0;
     for (int p = 0; p < N; p++) {
       float* l = &lp[(size_t)p * C];
@@ -154,6 +182,7 @@ struct Model {
       }
     }
     long long ev = 0;
+    float run_min = 3.0e38f;
     while (!q.empty()) {
       const Key top = *q.begin();
       const int r = top.r;
@@ -161,6 +190,10 @@ struct Model {
       bool tied = false;
       { auto it = q.begin(); ++it; if (it != q.end() && it->p == top.p) tied = true; }
       steps++; ev++;
+      if (parallel_study) {
+        if (top.p <= run_min) { close_super_event(); n_roots++; run_min = top.p; }
+        cur_root_events++;
+      }
       tied_steps += tied;
       if (track) {
         // suffix minima of the popped priorities (non-strict): entries above the new one leave
@@ -176,6 +209,7 @@ struct Model {
       int mc;
       const float f = score(x, y, S[r], &mc);
       touch(x, ev); touch(y, ev);
+      if (parallel_study) { cur_fp.push_back(x); cur_fp.push_back(y); }
       if (f != top.p) { store(r, f); last_refreshed = r; continue; }
       if (last_refreshed == r) repop_merges++;
       last_refreshed = -1;
@@ -207,6 +241,7 @@ struct Model {
       for (auto& kv : adj[b]) {
         const int c3 = kv.first, t = kv.second;
         touch(c3, ev);
+        if (parallel_study) cur_fp.push_back(c3);
         adj[c3].erase(b);
         // a record modified (or retired) while its stored priority equals that of an event on the stack -- an
         // ancestor of this event or the event itself: it is a tied sibling whose turn might have come first
@@ -236,6 +271,33 @@ struct Model {
     }
   }
 
+  void finish_study() {
+    if (!parallel_study) return;
+    close_super_event();
+    int b = 0; while ((1LL << (b + 1)) <= batch_len && b < 15) b++;
+    batch_hist[b]++; n_batches++;
+  }
+  // Rounds of an executor that looks at the next K super-events in order and runs every one whose footprint is
+  // disjoint from ALL earlier ones in its window (run or not); the others wait for the next round.
+  void window_study(int K) {
+    std::vector<long long> mark(N, 0);
+    std::vector<size_t> pending;
+    size_t next = 0;
+    long long rounds = 0, done = 0;
+    while (next < all_fp.size() || !pending.empty()) {
+      while (pending.size() < (size_t)K && next < all_fp.size()) pending.push_back(next++);
+      rounds++;
+      std::vector<size_t> left;
+      for (size_t i : pending) {
+        bool clash = false;
+        for (int o : all_fp[i]) if (mark[o] == rounds) { clash = true; break; }
+        for (int o : all_fp[i]) mark[o] = rounds;
+        if (clash) left.push_back(i); else done++;
+      }
+      pending.swap(left);
+    }
+    fprintf(stderr, "window study K = %d: %lld rounds for %lld super-events = %.1f per round\n", K, rounds, done, (double)done / (double)(rounds ? rounds : 1));
+  }
   int root(int p) { while (parent[p] != p) p = parent[p]; return p; }
 };
 
@@ -250,8 +312,16 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_ROUND")) m.round_to = atoi(e);
   if (const char* e = getenv("XM_REUSE")) m.reuse = atoi(e);
   if (const char* e = getenv("XM_GROWTH_PCT")) m.growth_pct = atoi(e);
+  if (const char* e = getenv("XM_PARALLEL")) m.parallel_study = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
+  m.finish_study();
+  if (m.parallel_study) {
+    fprintf(stderr, "parallel study: %lld pops, %lld root super-events (largest %lld pops), %lld batches of consecutive disjoint super-events: mean %.1f super-events = %.1f pops per batch; batch lengths by log2 bucket:", m.steps, m.n_roots, m.max_root_events, m.n_batches, (double)m.n_roots / (double)(m.n_batches ? m.n_batches : 1), (double)m.steps / (double)(m.n_batches ? m.n_batches : 1));
+    for (int i = 0; i < 16; i++) fprintf(stderr, " %lld", m.batch_hist[i]);
+    fprintf(stderr, "\n");
+    if (m.parallel_study >= 2) { m.window_study(16); m.window_study(64); m.window_study(256); }
+  }
   for (int p = 0; p < W * H; p++) { const int o = m.root(p); partition[p] = o; obj_class[p] = m.ocls[o]; }
   if (stats) {
     stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
