@@ -251,6 +251,16 @@ def test_exact_engine_relaunch_after_a_step_budget(oracle, monkeypatch):
     assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
     assert a[3]["finisher_steps"] == b[3]["finisher_steps"]
     assert oracle.masks_equivalent(b[0], b[1], g["mask"], g["object_class"])
+    # ... nor may the tie tracking (its nesting stack and counters travel through memory between launches): this
+    # vector has 86 tied pops and no conflict, cut or not
+    g = gu.load("cseg_blur_64x128_r2_s8001")
+    c = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
+    monkeypatch.delenv("MN_X_BUDGET")
+    d = _run(g, seg.MN_MODE_EXACT, tie_order=seg.MN_TIES_LOWEST_ID)
+    for k in ("finisher_steps", "merges", "tied_steps", "tied_merges", "tied_conflicts", "proof"):
+        assert c[3][k] == d[3][k], (k, c[3][k], d[3][k])
+    assert c[3]["tied_steps"] > 0 and c[3]["tied_conflicts"] == 0 and c[3]["proof"] == seg.MN_PROOF_SEQUENTIAL
+    assert np.array_equal(c[0], d[0])
 
 
 def test_exact_engine_python_variant(oracle):
@@ -522,5 +532,38 @@ def test_a_batch_with_more_images_than_compute_units():
             r = ref[i % 2]
             assert torch.equal(mask, r[0]) and torch.equal(part, r[2]), i
             assert (st["finisher_steps"], st["merges"], st["tied_steps"]) == (r[3]["finisher_steps"], r[3]["merges"], r[3]["tied_steps"]), i
+    finally:
+        batch.close()
+
+
+def test_a_batch_of_the_reference_order_loop_with_small_workspaces_and_budgets(oracle, monkeypatch, capfd):
+    """run_reforder_batch: images whose bucket arena or queue fills up are repeated with twice as much while the
+    others of the launch finish; a launch that has used up its pop budget is followed by another."""
+    import torch
+    monkeypatch.setenv("MN_X_BUDGET", "20000")
+    monkeypatch.setenv("MN_RO_ARENA_PER_PIXEL", "8")
+    monkeypatch.setenv("MN_RO_HEAP_PER_RECORD", "1")
+    monkeypatch.setenv("MN_TRACE_EXACT", "1")
+    names = ["cseg_synth_64x128_n15", "cseg_synth_64x128_n35", "cseg_synth_64x128_n60"]
+    gs = [gu.load(n) for n in names]
+    g0 = gs[0]
+    H, W, C = g0["spec"]["H"], g0["spec"]["W"], g0["spec"]["C"]
+    sdb, omf, bias = g0["spec"]["opts"]
+    o = seg.default_options(same_different_bias=sdb, object_merge_factor=omf, merge_logprob_bias=bias,
+                            mode=seg.MN_MODE_EXACT, clip_inputs=1, tie_order=seg.MN_TIES_REFERENCE)
+    cps = [torch.from_numpy(np.ascontiguousarray(g["class_probs"], dtype=np.float32)).cuda() for g in gs]
+    sps = [torch.from_numpy(np.ascontiguousarray(g["sameness_probs"], dtype=np.float32)).cuda() for g in gs]
+    batch = seg.ExactBatch(H, W, C, len(g0["offsets"]), len(gs))
+    try:
+        res = batch.segment(cps, sps, g0["offsets"], o)
+        err = capfd.readouterr().err
+        assert "status 3" in err or "status 4" in err          # (some image ran out of workspace and was repeated)
+        for n, g, (mask, table, part, st) in zip(names, gs, res):
+            ref = oracle.run_csegment(g["class_probs"], g["sameness_probs"], C, g["offsets"], sdb, omf, bias)
+            assert st["tie_order_used"] == seg.MN_TIES_REFERENCE
+            assert st["proof"] in (seg.MN_PROOF_CERTIFICATE, seg.MN_PROOF_SEQUENTIAL)      # (separable maps: certified, too)
+            assert st["finisher_steps"] == ref.stats["n_pops"], (n, st["finisher_steps"], ref.stats["n_pops"])
+            assert oracle.masks_equivalent(mask.cpu().numpy(), seg._class_list(table.cpu().numpy()),
+                                           g["mask"], g["object_class"]), (n, st)
     finally:
         batch.close()
