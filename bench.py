@@ -251,8 +251,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=0,
                     help="merger contexts in rotation on the one compute stream (launch of image i precedes the "
                          "read-back of image i - contexts + 1); 0 = by run length: 16 for 200 steps and more "
-                         "(0.128 against 0.131 ms per step with 8), 8 for short runs, where a deeper ring only "
-                         "lengthens the drain at the end (20 steps: 0.158 ms with 8, 0.168 with 16)")
+                         "(0.128 against 0.131 ms per step with 8), 6 for short runs, where a deeper ring only "
+                         "lengthens the drain at the end (20 steps, three runs each on one box: 0.157 ms with 4, "
+                         "0.153 with 6, 0.159 with 8, 0.163 with 12: profiles/r04_ring_depth_sweep.log)")
     ap.add_argument("--spin-seconds", type=float, default=2.5,
                     help="untimed: run the loop this long before the warm-up steps, so that the timed steps see "
                          "the GPU's sustained clocks instead of its idle power state")
@@ -271,7 +272,7 @@ def main():
                     help="images in flight per GPU (contexts + host threads + streams); 1 = serial")
     args = ap.parse_args()
     if args.contexts <= 0:
-        args.contexts = 16 if args.steps >= 200 else 8
+        args.contexts = 16 if args.steps >= 200 else 6
 
     import numpy as np
     import torch
