@@ -80,6 +80,11 @@ struct Model {
     cur_fp.clear(); cur_root_events = 0;
   }
   // ---- arena accounting (design aid): what the engine's adjacency arena would need under a policy ----
+  // ---- pair-table accounting (design aid, XM_REKEY=1): live records whose key is no longer the pixel pair they
+  // were created with -- what a pair table would hold if records with their original key were found by arithmetic ----
+  int rekey_study = 0;
+  std::vector<unsigned char> rekeyed;
+  long long live_rekeyed = 0, peak_rekeyed = 0, live_at_peak = 0, live_records = 0, n_start = 0;
   int cap0 = 64, growth = 4, round_to = 64, reuse = 0, growth_pct = 0;
   std::vector<int> acap, alen;                          // per object: capacity, entries in use (dead ones included)
   long long bump = 0, reallocs = 0, moved = 0;
@@ -161,6 +166,7 @@ struct Model {
     }
     const size_t NL = (size_t)N * O;
     r1.assign(NL, -1); r2.assign(NL, -1); S.assign(NL, 0.0f); prio.assign(NL, -1.0f);
+    if (rekey_study) rekeyed.assign(NL, 0);
     for (int p = 0; p < N; p++) {
       const int row = p / W, col = p % W;
       for (int k = 0; k < O; k++) {
@@ -171,6 +177,7 @@ struct Model {
         const float diff = (float)log(1.0 - (double)sp);
         const float same = logf(sp);
         const int r = p * O + k;
+        live_records++;
         r1[r] = std::min(p, qx); r2[r] = std::max(p, qx);
         S[r] = same - diff;
         adj[p][qx] = r; adj[qx][p] = r;
@@ -182,6 +189,7 @@ struct Model {
       }
     }
     long long ev = 0;
+    n_start = live_records;
     float run_min = 3.0e38f;
     while (!q.empty()) {
       const Key top = *q.begin();
@@ -218,6 +226,8 @@ struct Model {
       if (osize[a] < osize[b]) std::swap(a, b);
       merges++; tied_merges += tied;
       q.erase(top); prio[r] = -1.0f; r2[r] = -1;
+      live_records--;
+      if (rekey_study && rekeyed[r]) live_rekeyed--;
       ocls[a] = mc;
       osize[a] += osize[b];
       float* la = &lp[(size_t)a * C];
@@ -254,8 +264,14 @@ struct Model {
           S[tr] += S[t];
           if (prio[t] >= 0.0f) q.erase(Key{prio[t], t});
           prio[t] = -1.0f; r2[t] = -1;
+          live_records--;
+          if (rekey_study && rekeyed[t]) live_rekeyed--;
         } else {
           tr = t;
+          if (rekey_study && !rekeyed[t]) {
+            rekeyed[t] = 1;
+            if (++live_rekeyed > peak_rekeyed) { peak_rekeyed = live_rekeyed; live_at_peak = live_records; }
+          }
           sibling_check(prio[t]);
           r1[t] = std::min(a, c3); r2[t] = std::max(a, c3);
           adj[a][c3] = t; adj[c3][a] = t;
@@ -313,6 +329,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_REUSE")) m.reuse = atoi(e);
   if (const char* e = getenv("XM_GROWTH_PCT")) m.growth_pct = atoi(e);
   if (const char* e = getenv("XM_PARALLEL")) m.parallel_study = atoi(e);
+  if (const char* e = getenv("XM_REKEY")) m.rekey_study = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   m.finish_study();
@@ -322,6 +339,9 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     fprintf(stderr, "\n");
     if (m.parallel_study >= 2) { m.window_study(16); m.window_study(64); m.window_study(256); }
   }
+  if (m.rekey_study)
+    fprintf(stderr, "re-key study: %lld records at the start; at most %lld live records carried a key other than their pixel pair (%.1f %% of the start; %lld records were live then)\n",
+            m.n_start, m.peak_rekeyed, 100.0 * (double)m.peak_rekeyed / (double)(m.n_start ? m.n_start : 1), m.live_at_peak);
   for (int p = 0; p < W * H; p++) { const int o = m.root(p); partition[p] = o; obj_class[p] = m.ocls[o]; }
   if (stats) {
     stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
