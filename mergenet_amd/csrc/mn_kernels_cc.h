@@ -700,6 +700,9 @@ __global__ __launch_bounds__(256) void mn_count_cross_edges(ImgParams P, const i
 #ifndef MN_CC_SUM_AHEAD
 #define MN_CC_SUM_AHEAD 1   /* planes in flight ahead of the one in use: 1 at 1024 threads measured best (37.3 us by events; 2: 41.4, 3: 42.4; 512 threads: 43.7 / 40.8; 256: 47.6) -- occupancy matters more */
 #endif
+#ifndef MN_CC_SUMS_WAVE
+#define MN_CC_SUMS_WAVE 1     /* a wave inside one component: ONE LDS atomic per class (0: one per 16-lane row) */
+#endif
 #define MN_CC_SUM_SLOTS 64
 __device__ __forceinline__ int mn_lds_root_slot(int* s_root, int root) {
   unsigned h = ((unsigned)root * 2654435761u) >> 26;             // 6 bits
@@ -899,6 +902,17 @@ __device__ __forceinline__ i64 mn_row16_sum(i64 x) {
   return (i64)hi << 32 | (i64)(unsigned)lo;
 }
 
+// ... and over the four rows of a wave, from a value every lane of a row already holds: four lane reads on
+// the scalar unit (no LDS, no further DPP)
+__device__ __forceinline__ i64 mn_rows4_sum(i64 rs) {
+  const int lo = (int)(rs & 0xFFFFFFFFll), hi = (int)(rs >> 32);
+  i64 t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    t += (i64)__builtin_amdgcn_readlane(hi, 16 * k) << 32 | (i64)(unsigned)__builtin_amdgcn_readlane(lo, 16 * k);
+  return t;
+}
+
 __device__ __forceinline__ int mn_row16_min(int x) {
   x = min(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
   x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
@@ -983,8 +997,13 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
         for (int a = 0; a < G; a++) {
           if (c0 + a >= P.C) break;
           if (uni) {
+#if MN_CC_SUMS_WAVE
+            const i64 ws = mn_rows4_sum(mn_row16_sum((i64)g[a]));
+            if (lane == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, ws);
+#else
             const i64 rs = mn_row16_sum((i64)g[a]);
             if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, rs);
+#endif
           } else {
             mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, c0 + a, s0, (i64)g[a]);
           }
@@ -993,9 +1012,21 @@ __global__ __launch_bounds__(MN_CC_SUM_THREADS) void mn_cc_sums(
       const int lo1 = min(min((int)b.x, (int)b.y), min((int)b.z, (int)b.w));
       const int hi1 = max(max((int)b.x, (int)b.y), max((int)b.z, (int)b.w));
       if (uni) {
+#if MN_CC_SUMS_WAVE
+        int lo = mn_row16_min(lo1), hi = -mn_row16_min(-hi1);
+        lo = min(min(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, 16)),
+                 min(__builtin_amdgcn_readlane(lo, 32), __builtin_amdgcn_readlane(lo, 48)));
+        hi = max(max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 16)),
+                 max(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(hi, 48)));
+        if (lane == 0) {
+          mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 256);
+          mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo, hi);
+        }
+#else
         if ((lane & 15) == 0) mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 64);
         const int lo = mn_row16_min(lo1), hi = -mn_row16_min(-hi1);
         if ((lane & 15) == 0) mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo, hi);
+#endif
       } else {
         mn_cc_add(P, S, s_root, s_val, lp_acc, r.x, P.C, s0, 4);
         mn_cc_cls(s_min, s_max, clsmin, clsmax, r.x, s0, lo1, hi1);
