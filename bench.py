@@ -540,9 +540,11 @@ def main():
     if rank == 0:
         plane_bytes = 4.0 * H * W
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_components_1024x2048.json")
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_components_1024x2048.json")
+        pmc_path = ""
+        for rnd in ("r04", "r03", "r02"):            # the latest round's counter passes (tools/pmc_kernel.sh)
+            pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_components_1024x2048.json" % rnd)
+            if os.path.exists(pmc_path):
+                break
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh).get("hbm_bytes_per_launch", {})
