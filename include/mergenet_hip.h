@@ -189,8 +189,9 @@ typedef struct mn_stats {
                                   they do not (radius-4 blurred, clipped maps)                             */
   int tied_merges;             /* ... of which were merges */
   int tie_order_used;          /* MN_MODE_EXACT: MN_TIES_LOWEST_ID or MN_TIES_REFERENCE (0 on the other paths) */
-  int tied_conflicts;          /* MN_MODE_EXACT: 0 = no tied pop's choice touched what another tied choice touched:
-                                  the tied merges commute and every order among equals ends in this state (then
+  int tied_conflicts;          /* MN_MODE_EXACT: 0 = no tied pop's choice WROTE an object's state that another tied
+                                  choice read or wrote (a merge writes its two ends and reads their neighbours):
+                                  the tied events commute and every order among equals ends in this state (then
                                   proof == 2 even with tied_steps > 0); > 0 = at least one did (the engine stops
                                   looking at the first: a yes / no, not a count).  mn_kernels_exact.h "ties"      */
 } mn_stats;

@@ -267,7 +267,7 @@ static int x_ensure(mn_context* c, int N, int O, int C) {
       const size_t o_hs = take(nbuckets * 4 * sizeof(XSlot)), o_rec = take(NL * sizeof(XRec)),
                    o_arena = take(arena_cap * sizeof(unsigned)), o_leaf = take(leaf_cap * sizeof(unsigned)),
                    o_lp = take(((size_t)N * C + 64) * sizeof(float)), o_obj = take((size_t)N * sizeof(XObj)),
-                   o_acap = take((size_t)N * sizeof(int)), o_ostamp = take((size_t)N * sizeof(unsigned)),
+                   o_acap = take((size_t)N * sizeof(int)), o_ostamp = take((size_t)N * 2 * sizeof(unsigned)),
                    o_ovf = take(ovf_cap * sizeof(unsigned)), o_l1g = take((size_t)MN_X_MAXBLOCKS * sizeof(u64)),
                    o_tstack = take((size_t)MN_X_TSTACK * sizeof(u64)), o_free = take((size_t)MN_X_FREE_CLASSES * sizeof(unsigned)),
                    o_ctl = take(sizeof(XCtl));
@@ -980,7 +980,7 @@ static int exact_setup(mn_context* c, const ImgParams& P, hipStream_t st) {
   const size_t N = (size_t)P.N;
   MN_HIP(hipMemsetAsync(X.hs, 0xFF, (size_t)X.nb * 4 * sizeof(XSlot), st));
   MN_HIP(hipMemsetAsync(X.leaf, 0, (((size_t)X.NB << X.Blog) + 1024) * sizeof(unsigned), st));
-  MN_HIP(hipMemsetAsync(X.ostamp, 0, N * sizeof(unsigned), st));
+  MN_HIP(hipMemsetAsync(X.ostamp, 0, (size_t)N * 2 * sizeof(unsigned), st));
   MN_HIP(hipMemsetAsync(X.freeheads, 0xFF, MN_X_FREE_CLASSES * sizeof(unsigned), st));
   memset(w.h_ctl, 0, sizeof(XCtl));
   w.h_ctl->ttrack = getenv("MN_X_NO_TIE_TRACKING") ? 0 : 1;          // (timing comparisons)

@@ -121,7 +121,7 @@ struct XState {
   int* mlog;                  // diagnostic (MN_X_MERGELOG): 4 ints per merge {survivor, absorbed, record, priority bits}
   long long mlog_cap;         // merges the log holds (0: none)
   int dbg;                    // bit 0 (MN_X_FORCE_RELOCATE, tests): a slow insert moves an occupant whenever it can
-  unsigned* ostamp;           // [N] index of the last event (pop) that touched the object: tie-conflict tracking
+  unsigned* ostamp;           // [2 N] per object {last event that WROTE its state, last event that read it}: tie-conflict tracking
   u64* tstack;                // [MN_X_TSTACK] the nesting stack between launches
   XCtl* ctl;
 };
@@ -484,14 +484,19 @@ __device__ __forceinline__ void mn_x_group_refresh(u64* l1, u64* l2, int g, int 
 // rival.  Events (pops) nest: event j hangs under the last earlier event i with word(i) <= word(j) such that every
 // event between them is above word(i) -- the suffix minima of the popped words, kept as a stack (words
 // non-decreasing, event indices increasing).  Two SIBLINGS with equal words are what a tie rule orders; their
-// subtrees (everything popped above their word before the queue falls back to it) commute iff they touch
-// disjoint objects.  ostamp[o] = index of the last event that touched object o (endpoints of a pop, third
-// objects of a merge).  An event touching an object whose last toucher s lies in the subtree of a tied sibling of
-// one of its ancestors-or-self is a CONFLICT: with the stack, that is "the first entry with index > s and the
-// entry before it carry the same word".  Second kind: a merge re-scores or retires a record whose stored word
+// subtrees (everything popped above their word before the queue falls back to it) commute unless one WRITES the
+// state of an object the other reads or writes.  A merge writes the state of its two ends; a pop that only stores
+// a fresh priority reads its two ends; a merge reads its third objects (it rewrites their records with the merged
+// pair -- every such record has an end the merge writes, and every record an event reads has both ends touched,
+// so records need no stamps of their own).  ostamp[2 o] = index of the last event that wrote object o,
+// ostamp[2 o + 1] = of the last that read it (not overwritten while that stamp is dangerous, so that a later read
+// from the toucher's own subtree cannot hide it).  A stamp s is DANGEROUS for the current event when it lies in
+// the subtree of a tied sibling of one of the event's ancestors-or-self: with the stack, "the first entry with
+// index > s and the entry before it carry the same word".  Conflict: a read meets a dangerous write stamp, or a
+// write meets a dangerous write or read stamp.  Second kind: a merge re-scores or retires a record whose stored word
 // equals the word of an entry on the stack that was popped while tied -- a rival whose own turn might have come
 // first.  No conflict in a whole run => every order among equals gives the same final state (DESIGN.md
-// section 5); tests/tools/exact_model.cpp implements the same criterion on the CPU.
+// section 5); tests/tools/exact_model.cpp implements the same criterion on the CPU (XM_RW=1).
 // Stack entry: word << 32 | event index << 1 | popped-while-tied.
 __device__ __forceinline__ unsigned mn_x_te_word(u64 e) { return (unsigned)(e >> 32); }
 __device__ __forceinline__ unsigned mn_x_te_ev(u64 e) { return ((unsigned)e) >> 1; }
@@ -678,12 +683,13 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     uint4 rraw = pred_raw;
     uint4 ox, oy;
     int capx, capy;
-    unsigned sx = 0u, sy = 0u;
+    uint2 stx = make_uint2(0u, 0u), sty = make_uint2(0u, 0u);   // {write stamp, read stamp} of both ends
     float ax0 = 0.0f, ay0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f;
 #define MN_X_LOAD_OBJECTS(x_, y_) do {                                                                     \
       ox = *reinterpret_cast<const uint4*>(&X.obj[x_]); oy = *reinterpret_cast<const uint4*>(&X.obj[y_]);  \
       capx = X.acap[x_]; capy = X.acap[y_];                                                                \
-      if (track) { sx = X.ostamp[x_]; sy = X.ostamp[y_]; }                                                 \
+      if (track) { stx = *reinterpret_cast<const uint2*>(&X.ostamp[2 * (size_t)(x_)]);                     \
+                   sty = *reinterpret_cast<const uint2*>(&X.ostamp[2 * (size_t)(y_)]); }                   \
       if (lane < C) { ax0 = X.lp[(size_t)(x_) * C + lane]; ay0 = X.lp[(size_t)(y_) * C + lane]; }          \
       if (lane + 64 < C) { ax1 = X.lp[(size_t)(x_) * C + lane + 64]; ay1 = X.lp[(size_t)(y_) * C + lane + 64]; } \
     } while (0)
@@ -780,8 +786,27 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
     const unsigned fw = mn_x_word(f);
     steps++;
     if (track) {
-      if (lane == 0) { X.ostamp[x] = ev; X.ostamp[y] = ev; }
-      if (tpairs > 0 && (mn_x_tie_touch_uniform(sh_stk, tdepth, sx, lane) || mn_x_tie_touch_uniform(sh_stk, tdepth, sy, lane))) {
+      // a merge WRITES the state of both ends, a pop that only stores a fresh priority READS it: a conflict is a
+      // write stamp from a tied sibling's subtree, or -- for a merge -- a read stamp from one.  A read stamp is not
+      // overwritten while it is dangerous (a later read from this subtree must not hide it from a write).
+      const bool merging = P.variant == MN_VARIANT_CSEGMENT ? (fw == gword) : (fw >= gword);
+      bool drx = false, dry = false, conf = false;
+      if (tpairs > 0) {
+        drx = mn_x_tie_touch_uniform(sh_stk, tdepth, stx.y, lane);
+        dry = mn_x_tie_touch_uniform(sh_stk, tdepth, sty.y, lane);
+        conf = mn_x_tie_touch_uniform(sh_stk, tdepth, stx.x, lane) || mn_x_tie_touch_uniform(sh_stk, tdepth, sty.x, lane) ||
+               (merging && (drx || dry));
+      }
+      if (lane == 0) {
+        if (merging) {
+          *reinterpret_cast<uint2*>(&X.ostamp[2 * (size_t)x]) = make_uint2(ev, ev);
+          *reinterpret_cast<uint2*>(&X.ostamp[2 * (size_t)y]) = make_uint2(ev, ev);
+        } else {
+          if (!drx) X.ostamp[2 * (size_t)x + 1] = ev;
+          if (!dry) X.ostamp[2 * (size_t)y + 1] = ev;
+        }
+      }
+      if (conf) {
         tied_conflicts++;
         track = false;
       }
@@ -903,13 +928,13 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       float Su = 0.0f;
       unsigned u_rid = MN_X_INVALID;
       float v3[16];
-      unsigned s3 = 0u;
+      uint2 st3 = make_uint2(0u, 0u);
 #pragma unroll
       for (int q = 0; q < 16; q++) v3[q] = 0.0f;
       if (live) {
         const float* l3 = X.lp + (size_t)c3 * C;
         const uint4 o3 = *reinterpret_cast<const uint4*>(&X.obj[c3]);
-        if (track) { s3 = X.ostamp[c3]; X.ostamp[c3] = ev; }
+        if (track) st3 = *reinterpret_cast<const uint2*>(&X.ostamp[2 * (size_t)c3]);
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (4 * q < C) {     // (16-byte loads; what lies behind the object's C terms is read and ignored)
@@ -940,7 +965,10 @@ __global__ __launch_bounds__(64) void mn_x_run(const ImgParams* __restrict__ Ps,
       const bool fold = live && found >= 0;
       const bool adopt = live && found < 0;
       if (track) {
-        bool conf = live && tpairs > 0 && mn_x_tie_touch_lane(sh_stk, tdepth, s3);
+        // a third object's state is READ (its records with the merged pair are rewritten; every such record has an
+        // end this merge writes): a conflict only with a write from a tied sibling's subtree
+        bool conf = live && tpairs > 0 && mn_x_tie_touch_lane(sh_stk, tdepth, st3.x);
+        if (live && !(tpairs > 0 && mn_x_tie_touch_lane(sh_stk, tdepth, st3.y))) X.ostamp[2 * (size_t)c3 + 1] = ev;
         if (rivals) {
           const unsigned oldw_u = fold ? X.leaf[u_rid] : 0u;
           conf = conf || (live && (mn_x_tie_rival_lane(sh_stk, tdepth, oldw_t) || mn_x_tie_rival_lane(sh_stk, tdepth, oldw_u)));

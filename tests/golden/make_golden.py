@@ -164,6 +164,13 @@ def cseg_specs(big: bool):
         specs.append(dict(name="cseg_synth_800x1333_cfg5", kind="synth", H=800, W=1333, C=81,
                           offsets=[80, 16], seed=1000, noise=0.15, occlusion=True,
                           opts=(0.0, 1.0, 0.03)))
+        # (round 4) network-like maps at the BASELINE size: continuous values (certainty fades at the instance
+        # boundaries), so bit-equal priorities are rare and far apart -- what the default mode's proof looks like
+        # on inputs without synth-v1's plateaus
+        specs.append(dict(name="cseg_blur_1024x2048_r2_s4242", kind="blur", H=1024, W=2048, C=9, offsets=[40, 10],
+                          seed=4242, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
+        specs.append(dict(name="cseg_blur_512x1024_r2_s4243", kind="blur", H=512, W=1024, C=9, offsets=[40, 10],
+                          seed=4243, radius=2, noise=0.05, opts=(0.0, 1.0, 0.03)))
         for sd in (1000, 1001, 1002):  # the size the reference's own caller uses (segment.py:93)
             specs.append(dict(name="cseg_synth_512x1024_s%d" % sd, kind="synth", H=512, W=1024,
                               C=9, offsets=[40, 10], seed=sd, noise=0.15, opts=(0.0, 1.0, 0.03)))

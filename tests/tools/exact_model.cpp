@@ -133,29 +133,53 @@ struct Model {
 
   // touch of object o by event `ev` (popped priority pw): conflict iff the last toucher lies in the subtree
   // of a tied sibling of one of ev's ancestors-or-self
-  void touch(int o, long long ev) {
-    if (!track) return;
-    const long long s = stamp[o];
-    stamp[o] = ev;
-    if (s == 0 || tied_pairs_on_stack == 0) return;
+  bool dangerous(long long s) const {
+    if (s == 0 || tied_pairs_on_stack == 0) return false;
     // first stack entry with index > s
     size_t lo = 0, hi = stk.size();
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (stk[mid].second > s) hi = mid; else lo = mid + 1; }
-    if (lo == stk.size() || lo == 0) return;           // (s is the current event itself, or older than the whole stack)
-    if (stk[lo - 1].first == stk[lo].first) tied_conflicts++;
+    if (lo == stk.size() || lo == 0) return false;     // (s is the current event itself, or older than the whole stack)
+    return stk[lo - 1].first == stk[lo].first;
+  }
+  // rw = 0 (XM_RW=0, the first form of the criterion): every touch counts alike (an object touched from two tied subtrees is a conflict).
+  // rw = 1: a touch either WRITES the object's state (the two ends of a merge) or only READS it (the ends of a pop that
+  // stores a fresh priority; the third objects of a merge, whose records with the merged pair are rewritten): two
+  // tied subtrees commute unless one writes an object the other reads or writes.  Every record an event rewrites has
+  // an end the event writes and every record it reads has both ends touched, so records need no stamps of their own.
+  // The read stamp is not overwritten while it is dangerous (a later read from the toucher's own subtree must not
+  // hide it from a write that follows).
+  int rw = 1;
+  long long kind_count[4] = {0, 0, 0, 0};              // conflicts: write after write, read after write, write after read, rival
+  std::vector<long long> rstamp;
+  void touch(int o, long long ev, bool write = true) {
+    if (!track) return;
+    if (!rw) {
+      const long long s = stamp[o];
+      stamp[o] = ev;
+      if (dangerous(s)) tied_conflicts++;
+      return;
+    }
+    if (dangerous(stamp[o])) { tied_conflicts++; kind_count[write ? 0 : 1]++; }
+    if (write) {
+      if (dangerous(rstamp[o])) { tied_conflicts++; kind_count[2]++; }
+      stamp[o] = ev; rstamp[o] = ev;
+    } else if (!dangerous(rstamp[o])) {
+      rstamp[o] = ev;
+    }
   }
 
   void sibling_check(float old) {
     if (!track || old < 0.0f) return;
     size_t lo = 0, hi = stk.size();
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (stk[mid].first >= old) hi = mid; else lo = mid + 1; }
-    if (lo < stk.size() && stk[lo].first == old) tied_conflicts++;
+    if (lo < stk.size() && stk[lo].first == old) { tied_conflicts++; kind_count[3]++; }
   }
 
   void run(const float* cls_p, const float* same_p, const int* offs) {
     N = W * H;
     lp.resize((size_t)N * C); ocls.resize(N); osize.assign(N, 1); parent.resize(N); adj.resize(N);
     stamp.assign(N, 0);
+    if (rw) rstamp.assign(N, 0);
     if (parallel_study) batch_mark.assign(N, 0);
     acap.assign(N, cap0); alen.assign(N, 0); bump = (long long)N * cap0;
     for (int p = 0; p < N; p++) {
@@ -216,9 +240,10 @@ struct Model {
       const int x = r1[r], y = r2[r];
       int mc;
       const float f = score(x, y, S[r], &mc);
-      touch(x, ev); touch(y, ev);
+      const bool merging = f == top.p;
+      touch(x, ev, merging); touch(y, ev, merging);
       if (parallel_study) { cur_fp.push_back(x); cur_fp.push_back(y); }
-      if (f != top.p) { store(r, f); last_refreshed = r; continue; }
+      if (!merging) { store(r, f); last_refreshed = r; continue; }
       if (last_refreshed == r) repop_merges++;
       last_refreshed = -1;
       // merge
@@ -250,7 +275,7 @@ struct Model {
       int adopted_n = 0;
       for (auto& kv : adj[b]) {
         const int c3 = kv.first, t = kv.second;
-        touch(c3, ev);
+        touch(c3, ev, false);
         if (parallel_study) cur_fp.push_back(c3);
         adj[c3].erase(b);
         // a record modified (or retired) while its stored priority equals that of an event on the stack -- an
@@ -330,6 +355,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_GROWTH_PCT")) m.growth_pct = atoi(e);
   if (const char* e = getenv("XM_PARALLEL")) m.parallel_study = atoi(e);
   if (const char* e = getenv("XM_REKEY")) m.rekey_study = atoi(e);
+  if (const char* e = getenv("XM_RW")) m.rw = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   m.finish_study();
@@ -339,6 +365,9 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     fprintf(stderr, "\n");
     if (m.parallel_study >= 2) { m.window_study(16); m.window_study(64); m.window_study(256); }
   }
+  if (getenv("XM_KINDS"))
+    fprintf(stderr, "conflicts by kind: write after write %lld, read after write %lld, write after read %lld, rival record %lld\n",
+            m.kind_count[0], m.kind_count[1], m.kind_count[2], m.kind_count[3]);
   if (m.rekey_study)
     fprintf(stderr, "re-key study: %lld records at the start; at most %lld live records carried a key other than their pixel pair (%.1f %% of the start; %lld records were live then)\n",
             m.n_start, m.peak_rekeyed, 100.0 * (double)m.peak_rekeyed / (double)(m.n_start ? m.n_start : 1), m.live_at_peak);
