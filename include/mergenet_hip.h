@@ -77,8 +77,8 @@ enum mn_proof {
                                     MN_TIES_REFERENCE)                                                               */
   MN_PROOF_SEQUENTIAL_TIES = 3   /* the sequential order was run, but some pops chose among bit-equal priorities by
                                     the engine's rule (lowest record id) where the reference's std::priority_queue
-                                    chooses by heap position: equal to the reference on every vector held at these
-                                    sizes, differing on the radius-4 blurred vectors; require_proof = 1 redoes such an
+                                    chooses by heap position: equal to the reference on most vectors held at the
+                                    benchmark's sizes, differing on the radius-4 blurred ones and on one blurred 1024x2048; require_proof = 1 redoes such an
                                     image in the reference's order                                                   */
 };
 #define MN_TIE_LIMIT_RECORDS 400000   /* MN_TIES_DEFAULT: largest image (initial records) redone in the reference's order */
