@@ -200,22 +200,34 @@ def default_mode_block(seg, pool_images, seeds, offs, device, max_batch):
         batch = None
         try:
             batch = seg.ExactBatch(H, W, C, O, count, device=device)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            res = batch.segment([pool_images[i % len(pool_images)][0] for i in range(count)],
-                                [pool_images[i % len(pool_images)][1] for i in range(count)], offs, o_exact)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t
+            cps = [pool_images[i % len(pool_images)][0] for i in range(count)]
+            sps = [pool_images[i % len(pool_images)][1] for i in range(count)]
+            # two launches: the first allocates and sets up the workspaces (what a first call pays), the second is
+            # what a service that keeps its workspaces pays per batch -- the figure reported as `value`
+            secs = []
+            res = None
+            for _launch in range(2):
+                del res
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                res = batch.segment(cps, sps, offs, o_exact)
+                torch.cuda.synchronize()
+                secs.append(time.perf_counter() - t)
+            dt = secs[1]
             eq = [equal(mk, tb, s_, goldens[i % len(pool_images)]) for i, (mk, tb, _, s_) in enumerate(res)]
             proofs = sorted({r[3]["proof"] for r in res})
             ws = batch.mergers[0].workspace_bytes()
             batch_out = {"images_per_launch": count, "seconds": round(dt, 3),
                          "value": round(count * H * W / dt / 1e6, 4), "unit": "Mpixel/s",
+                         "first_launch_seconds": round(secs[0], 3),
+                         "first_launch_value": round(count * H * W / secs[0] / 1e6, 4),
                          "proof": proofs, "tied_conflicts_any": bool(any(r[3]["tied_conflicts"] > 0 for r in res)),
                          "all_equal_reference": bool(all(e for e in eq if e is not None)) if any(e is not None for e in eq) else None,
                          "workspace_bytes_per_image": int(ws),
-                         "how": "one mn_segment_exact_batch launch, a workgroup per image; seconds include allocating "
-                                "and setting up the %d workspaces" % count}
+                         "how": "mn_segment_exact_batch, a workgroup per image in ONE launch, run twice on the same %d "
+                                "workspaces: `seconds` / `value` are the second launch (a service keeps its workspaces; "
+                                "its results are the ones compared with the reference), `first_launch_*` include "
+                                "allocating and setting them up" % count}
             del res
             break
         except Exception as e:                                # noqa: BLE001 -- a side measurement must not fail the line
