@@ -155,6 +155,9 @@ __global__ __launch_bounds__(64) void mn_ro_loop(const RoState* __restrict__ Ss,
 #define MN_RO_STAMP(acc)
 #endif
   long long t_init = 0, t_pop = 0, t_merge = 0, t_mark = 0;    // (-DMN_RO_STAMPS: 100 MHz ticks per phase, MN_TRACE_EXACT prints them)
+#ifdef MN_RO_STAMPS
+  t_mark = wall_clock64();
+#endif
   (void)t_mark;
   // ---- the constructor's loop (segment.cc:209-231): the maps are built (mn_ro_build_maps); the pushes, in
   //      creation order, 64 records per look ----
