@@ -65,6 +65,13 @@ __global__ __launch_bounds__(64) void mn_ro_build_maps(ImgParams P, RoState S, i
 // hole over five levels are fetched together and the path through them is settled by cross-lane reads.  The
 // MOVES are those of std::push_heap / std::pop_heap (mn_ro_push / mn_ro_pop are the scalar text the host
 // checks against the library; the GPU tests check this form against the same vectors).
+// value of lane `l` for a WAVE-UNIFORM l: a lane read on the scalar unit (v_readlane), not a trip through the LDS
+// crossbar (ds_bpermute, ~100 cycles) -- the descent of a pop is a chain of 2 x 26 of them
+__device__ __forceinline__ int mn_ro_lane(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ float mn_ro_lane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
+}
+
 __device__ __forceinline__ void mn_ro_wave_pushup(const RoState& S, long long hole, float pr, int rec, int lane) {
   // lane l: the ancestor at distance l + 1 of the hole (1-based index (hole + 1) >> (l + 1))
   const long long j = lane < 48 ? ((hole + 1) >> (lane + 1)) : 0;
@@ -96,9 +103,9 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
     const long long idx0 = lane < 62 ? (long long)lane + 1 : (lane == 62 ? 0 : len);
     if (idx0 < n) { const unsigned long long e = S.heap[idx0]; p = mn_ro_entry_prio(e); rr = mn_ro_entry_rec(e); }
   }
-  *pr_out = __shfl(p, 62); *rec_out = __shfl(rr, 62);
-  const float vp = __shfl(p, 63);
-  const int vr = __shfl(rr, 63);
+  *pr_out = mn_ro_lane(p, 62); *rec_out = mn_ro_lane(rr, 62);
+  const float vp = mn_ro_lane(p, 63);
+  const int vr = mn_ro_lane(rr, 63);
   *rec_prio = S.prio[*rec_out];                          // (uniform loads, in flight while the hole goes down)
   *rec_r2 = S.r2[*rec_out];
   n = len;
@@ -120,8 +127,8 @@ __device__ __forceinline__ void mn_ro_wave_pop(const RoState& S, long long& n, f
     for (int lev = 1; lev <= 5; lev++) {
       if (cur < half) {                                  // (uniform: cur is the same in every lane)
         const int lr = (1 << lev) - 2 + 2 * curj + 1, ll = lr - 1;
-        const float pR = __shfl(p, lr), pL = __shfl(p, ll);
-        const int chosen = (pR < pL) ? ll : lr;          // the right child among equals
+        const float pR = mn_ro_lane(p, lr), pL = mn_ro_lane(p, ll);
+        const int chosen = __builtin_amdgcn_readfirstlane((pR < pL) ? ll : lr);          // the right child among equals
         if (lane == chosen) S.heap[cur] = mn_ro_entry(p, rr);
         curj = chosen - ((1 << lev) - 2);
         cur = (((hole + 1) << lev) + curj) - 1;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(64) void mn_ro_loop(const RoState* __restrict__ Ss,
         const int l = __ffsll((long long)want) - 1;
         want &= want - 1ull;
         if (n >= S.hcap) { status = MN_RO_HEAP_FULL; break; }
-        mn_ro_wave_pushup(S, n, __shfl(pr, l), (int)(r + l), lane);
+        mn_ro_wave_pushup(S, n, mn_ro_lane(pr, l), (int)(r + l), lane);
         n++;
         biggest = n > biggest ? n : biggest;
       }
@@ -198,11 +205,11 @@ __global__ __launch_bounds__(64) void mn_ro_loop(const RoState* __restrict__ Ss,
       if (second < 0) continue;                           // a merged record (segment.cc:557)
       float f = 0.0f; int mc = 0;
       if (lane == 0) { f = mn_ro_score(S, rec, &mc); S.prio[rec] = f; }
-      f = __shfl(f, 0);
+      f = mn_ro_lane(f, 0);
       if (f == q) {
         int a = 0, b = 0, it = MN_RO_NULL, rc = MN_RO_RUNNING;
         if (lane == 0) rc = mn_ro_merge_begin(S, rec, mc, &a, &b, &it);
-        rc = __shfl(rc, 0); it = __shfl(it, 0); a = __shfl(a, 0); b = __shfl(b, 0);
+        rc = mn_ro_lane(rc, 0); it = mn_ro_lane(it, 0); a = mn_ro_lane(a, 0); b = mn_ro_lane(b, 0);
         // The walk over the absorbed object's records, up to 64 at a time: lane 0 follows the list (the
         // iteration order of the reference's unordered_map), then every lane takes ONE record -- out of the
         // third object's map, look-up in the survivor's, fold or re-key, into the third object's map, fresh
@@ -224,20 +231,20 @@ __global__ __launch_bounds__(64) void mn_ro_loop(const RoState* __restrict__ Ss,
           unsigned long long akey = 0ull;
           if (node != MN_RO_NULL) myrc = mn_ro_merge_node(S, a, b, node, &nx, &pp, &prec, 1, &akey);
           const unsigned long long failed = __ballot(myrc != MN_RO_RUNNING);
-          if (failed) { rc = __shfl(myrc, __ffsll((long long)failed) - 1); break; }
+          if (failed) { rc = mn_ro_lane(myrc, __ffsll((long long)failed) - 1); break; }
           for (int i = 0; i < cnt && rc == MN_RO_RUNNING; i++) {          // (uniform)
-            const unsigned klo = (unsigned)__shfl((int)(akey & 0xFFFFFFFFull), i), khi = (unsigned)__shfl((int)(akey >> 32), i);
-            const int nd = __shfl(node, i);
+            const unsigned klo = (unsigned)mn_ro_lane((int)(akey & 0xFFFFFFFFull), i), khi = (unsigned)mn_ro_lane((int)(akey >> 32), i);
+            const int nd = mn_ro_lane(node, i);
             const unsigned long long k = ((unsigned long long)khi << 32) | klo;
             if (k != 0ull) {
               int ok = 1;
               if (lane == 0) ok = mn_ro_insert(S, a, nd, k) ? 1 : 0;
-              if (!__shfl(ok, 0)) rc = MN_RO_ARENA_FULL;
+              if (!mn_ro_lane(ok, 0)) rc = MN_RO_ARENA_FULL;
             }
           }
           for (int i = 0; i < cnt && rc == MN_RO_RUNNING; i++) {
-            const int pr_rec = __shfl(prec, i);
-            const float pr_val = __shfl(pp, i);
+            const int pr_rec = mn_ro_lane(prec, i);
+            const float pr_val = mn_ro_lane(pp, i);
             if (pr_rec >= 0) {
               if (n >= S.hcap) { rc = MN_RO_HEAP_FULL; break; }
               mn_ro_wave_pushup(S, n, pr_val, pr_rec, lane);
