@@ -79,6 +79,44 @@ struct Model {
     if (cur_root_events > max_root_events) max_root_events = cur_root_events;
     cur_fp.clear(); cur_root_events = 0;
   }
+  // ---- a PREFIX executor (design aid, XM_ROUNDS=K): each round looks at the K best queue entries as they stand and
+  // commits the longest prefix of the SEQUENTIAL pop sequence that (a) pops exactly those entries, in their order,
+  // with the priorities they had at the start of the round (no record that an earlier pop of the round stored or
+  // re-scored comes in between), and (b) has pairwise compatible footprints (no object written by one and read or
+  // written by another).  Such a prefix can be executed side by side with the sequential result, bit for bit. ----
+  int rounds_k = 0;
+  std::vector<Key> rs_snap, rs_pre;
+  size_t rs_pos = 0;
+  std::vector<long long> rs_wmark, rs_rmark;
+  std::vector<int> rs_w, rs_r;
+  long long rs_round = 1, rs_rounds = 0, rs_in_round = 0, rs_cut_order = 0, rs_cut_clash = 0, rs_cut_window = 0;
+  std::vector<long long> rs_hist = std::vector<long long>(12, 0);
+  bool rs_unavailable = false;
+  void rs_begin(const Key& top) {
+    rs_unavailable = !(rs_pos < rs_snap.size() && rs_snap[rs_pos].r == top.r && rs_snap[rs_pos].p == top.p);
+    rs_pre.clear();
+    auto it = q.begin();
+    for (int i = 0; i < rounds_k && it != q.end(); ++i, ++it) rs_pre.push_back(*it);
+    rs_w.clear(); rs_r.clear();
+  }
+  void rs_end() {
+    bool clash = false;
+    for (int o : rs_w) if (rs_wmark[o] == rs_round || rs_rmark[o] == rs_round) { clash = true; break; }
+    if (!clash) for (int o : rs_r) if (rs_wmark[o] == rs_round) { clash = true; break; }
+    if (rs_unavailable || clash) {
+      if (rs_in_round > 0) {
+        rs_rounds++;
+        int b = 0; while ((1LL << (b + 1)) <= rs_in_round && b < 11) b++;
+        rs_hist[b]++;
+        if (rs_unavailable) { if (rs_pos >= rs_snap.size()) rs_cut_window++; else rs_cut_order++; } else rs_cut_clash++;
+      }
+      rs_round++; rs_in_round = 0;
+      rs_snap = rs_pre; rs_pos = 0;
+    }
+    rs_pos++; rs_in_round++;
+    for (int o : rs_w) { rs_wmark[o] = rs_round; rs_rmark[o] = rs_round; }
+    for (int o : rs_r) rs_rmark[o] = rs_round;
+  }
   // ---- arena accounting (design aid): what the engine's adjacency arena would need under a policy ----
   // ---- pair-table accounting (design aid, XM_REKEY=1): live records whose key is no longer the pixel pair they
   // were created with -- what a pair table would hold if records with their original key were found by arithmetic ----
@@ -181,6 +219,7 @@ struct Model {
     stamp.assign(N, 0);
     if (rw) rstamp.assign(N, 0);
     if (parallel_study) batch_mark.assign(N, 0);
+    if (rounds_k) { rs_wmark.assign(N, 0); rs_rmark.assign(N, 0); }
     acap.assign(N, cap0); alen.assign(N, 0); bump = (long long)N * cap0;
     for (int p = 0; p < N; p++) {
       float* l = &lp[(size_t)p * C];
@@ -222,6 +261,7 @@ struct Model {
       bool tied = false;
       { auto it = q.begin(); ++it; if (it != q.end() && it->p == top.p) tied = true; }
       steps++; ev++;
+      if (rounds_k) rs_begin(top);
       if (parallel_study) {
         if (top.p <= run_min) { close_super_event(); n_roots++; run_min = top.p; }
         cur_root_events++;
@@ -243,7 +283,8 @@ struct Model {
       const bool merging = f == top.p;
       touch(x, ev, merging); touch(y, ev, merging);
       if (parallel_study) { cur_fp.push_back(x); cur_fp.push_back(y); }
-      if (!merging) { store(r, f); last_refreshed = r; continue; }
+      if (rounds_k) { (merging ? rs_w : rs_r).push_back(x); (merging ? rs_w : rs_r).push_back(y); }
+      if (!merging) { store(r, f); last_refreshed = r; if (rounds_k) rs_end(); continue; }
       if (last_refreshed == r) repop_merges++;
       last_refreshed = -1;
       // merge
@@ -277,6 +318,7 @@ struct Model {
         const int c3 = kv.first, t = kv.second;
         touch(c3, ev, false);
         if (parallel_study) cur_fp.push_back(c3);
+        if (rounds_k) rs_r.push_back(c3);
         adj[c3].erase(b);
         // a record modified (or retired) while its stored priority equals that of an event on the stack -- an
         // ancestor of this event or the event itself: it is a tied sibling whose turn might have come first
@@ -309,6 +351,7 @@ struct Model {
       free_block(acap[b]);
       std::unordered_map<int, int>().swap(adj[b]);
       parent[b] = a;
+      if (rounds_k) rs_end();
     }
   }
 
@@ -356,6 +399,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_PARALLEL")) m.parallel_study = atoi(e);
   if (const char* e = getenv("XM_REKEY")) m.rekey_study = atoi(e);
   if (const char* e = getenv("XM_RW")) m.rw = atoi(e);
+  if (const char* e = getenv("XM_ROUNDS")) m.rounds_k = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   m.finish_study();
@@ -364,6 +408,13 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     for (int i = 0; i < 16; i++) fprintf(stderr, " %lld", m.batch_hist[i]);
     fprintf(stderr, "\n");
     if (m.parallel_study >= 2) { m.window_study(16); m.window_study(64); m.window_study(256); }
+  }
+  if (m.rounds_k) {
+    if (m.rs_in_round > 0) m.rs_rounds++;
+    fprintf(stderr, "prefix executor, window %d: %lld pops in %lld rounds = %.2f per round; a round ended because the next pop was not the next entry of the window %lld, the window was used up %lld, footprints clashed %lld; rounds by log2 of their length:",
+            m.rounds_k, m.steps, m.rs_rounds, (double)m.steps / (double)(m.rs_rounds ? m.rs_rounds : 1), m.rs_cut_order, m.rs_cut_window, m.rs_cut_clash);
+    for (int i = 0; i < 12; i++) fprintf(stderr, " %lld", m.rs_hist[i]);
+    fprintf(stderr, "\n");
   }
   if (getenv("XM_KINDS"))
     fprintf(stderr, "conflicts by kind: write after write %lld, read after write %lld, write after read %lld, rival record %lld\n",
