@@ -46,3 +46,22 @@ def test_a_tie_decided_vector_is_reported_as_conflicting():
     g, mask, classes, st = _run("cseg_blur4_128x256_s5100")
     assert st["steps"] == 115199 and st["tied_steps"] > 0 and st["tied_conflicts"] > 0, st
     assert not labels.masks_equivalent(mask, classes, g["mask"], g["object_class"])
+
+
+@pytest.mark.parametrize("window", [3, 16, 64])
+@pytest.mark.parametrize("name", ["cseg_adv_32x32_o0", "cseg_adv_48x48_o1", "cseg_synth_32x64_n60", "cseg_blur_64x128_r2",
+                                  "cseg_checker_96x128_b015"])
+def test_prefix_executor_reproduces_the_sequential_order(name, window, monkeypatch):
+    """The side-by-side executor sketched in DESIGN.md section 9 (XM_EXECUTOR=K in the model): per round the K best
+    queue entries are planned from the state at the START of the round, and the longest prefix is committed in which
+    no committed pop produced a queue key ahead of the next entry and no pop writes an object that an earlier one
+    read or wrote (or reads one it wrote).  Claim: the state after every round is the sequential one -- same
+    partition, same classes, same number of pops and merges as the sequential model."""
+    g = gu.load(name)
+    sdb, omf, bias = g["spec"]["opts"]
+    monkeypatch.delenv("XM_EXECUTOR", raising=False)
+    p0, c0, s0 = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias, track=False)
+    monkeypatch.setenv("XM_EXECUTOR", str(window))
+    p1, c1, s1 = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias, track=False)
+    assert np.array_equal(p0, p1) and np.array_equal(c0, c1)
+    assert (s0["steps"], s0["merges"]) == (s1["steps"], s1["merges"])

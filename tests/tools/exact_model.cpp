@@ -213,6 +213,150 @@ struct Model {
     if (lo < stk.size() && stk[lo].first == old) { tied_conflicts++; kind_count[3]++; }
   }
 
+  // ---- the prefix executor itself (XM_EXECUTOR=K): NOT a count along the sequential order but the algorithm a
+  // workgroup would run.  Per round: the K best queue entries; for each, from the state at the START of the round
+  // and without changing anything, a PLAN (fresh priority; for a merge the survivor's new state and, per record of
+  // the absorbed object, fold or adopt, new log-odds sum, new priority); then the longest prefix is committed such
+  // that no committed plan produced a queue key ahead of the next entry and no plan writes an object that an earlier
+  // committed plan read or wrote, or reads one it wrote.  The result must be the sequential model's, bit for bit
+  // (tests/test_exact_model.py compares partitions, pops and merges). ----
+  int executor_k = 0;
+  long long ex_rounds = 0;
+  struct PlanItem { int c3, t, tr; bool fold; float newS, newprio; };
+  struct Plan {
+    Key key; int r; bool merging; float f; int a, b, mc, newsize;
+    std::vector<float> newlp;
+    std::vector<PlanItem> items;
+    bool has_best; Key best;
+  };
+  float score_as(const float* la, int cls_a, int size_a, int o, float s_, int* mc) const {
+    float cdl = 0.0f;
+    int m = cls_a;
+    if (cls_a != ocls[o]) {
+      const float* lb = &lp[(size_t)o * C];
+      int best = 0;
+      float bestv = la[0] + lb[0];
+      for (int c = 1; c < C; c++) { const float v = la[c] + lb[c]; if (v > bestv) { bestv = v; best = c; } }
+      m = best;
+      cdl = bestv - la[cls_a] - lb[ocls[o]];
+    }
+    *mc = m;
+    const size_t den = (size_t)size_a + (size_t)osize[o];
+    return (s_ * omf + cdl) / den + bias;
+  }
+  void offer(Plan& P, float pr, int rid) const {
+    if (!(pr >= 0.0f)) return;
+    const Key k{pr, rid};
+    if (!P.has_best || k < P.best) { P.best = k; P.has_best = true; }
+  }
+  void make_plan(const Key& e, Plan& P) const {
+    P.key = e; P.r = e.r; P.items.clear(); P.newlp.clear(); P.has_best = false;
+    const int x = r1[e.r], y = r2[e.r];
+    P.f = score(x, y, S[e.r], &P.mc);
+    P.merging = P.f == e.p;
+    P.a = x; P.b = y;
+    if (!P.merging) { offer(P, P.f, e.r); return; }
+    if (osize[P.a] < osize[P.b]) std::swap(P.a, P.b);
+    const int a = P.a, b = P.b;
+    P.newsize = osize[a] + osize[b];
+    P.newlp.resize(C);
+    for (int c = 0; c < C; c++) P.newlp[c] = lp[(size_t)a * C + c] + lp[(size_t)b * C + c];
+    for (const auto& kv : adj[b]) {
+      const int c3 = kv.first, t = kv.second;
+      if (c3 == a) continue;
+      PlanItem it;
+      it.c3 = c3; it.t = t;
+      const auto hit = adj[a].find(c3);
+      it.fold = hit != adj[a].end();
+      it.tr = it.fold ? hit->second : t;
+      it.newS = it.fold ? S[it.tr] + S[t] : S[t];
+      int m2;
+      // (the record's ends are ordered by id; the score is symmetric in them up to which class vector is `la`: the
+      //  sequential code calls score(r1, r2) with r1 < r2 -- keep that order)
+      if (a < c3) it.newprio = score_as(P.newlp.data(), P.mc, P.newsize, c3, it.newS, &m2);
+      else it.newprio = score_rev(c3, P.newlp.data(), P.mc, P.newsize, it.newS, &m2);
+      offer(P, it.newprio, it.tr);
+      P.items.push_back(it);
+    }
+  }
+  // score(o, A') with o < a: the first operand is the untouched object, the second the survivor's NEW state
+  float score_rev(int o, const float* lb, int cls_b, int size_b, float s_, int* mc) const {
+    float cdl = 0.0f;
+    int m = ocls[o];
+    if (ocls[o] != cls_b) {
+      const float* la = &lp[(size_t)o * C];
+      int best = 0;
+      float bestv = la[0] + lb[0];
+      for (int c = 1; c < C; c++) { const float v = la[c] + lb[c]; if (v > bestv) { bestv = v; best = c; } }
+      m = best;
+      cdl = bestv - la[ocls[o]] - lb[cls_b];
+    }
+    *mc = m;
+    const size_t den = (size_t)osize[o] + (size_t)size_b;
+    return (s_ * omf + cdl) / den + bias;
+  }
+  void apply_plan(const Plan& P) {
+    steps++;
+    if (!P.merging) { store(P.r, P.f); return; }
+    merges++;
+    const int a = P.a, b = P.b, r = P.r;
+    q.erase(P.key); prio[r] = -1.0f; r2[r] = -1;
+    ocls[a] = P.mc; osize[a] = P.newsize;
+    for (int c = 0; c < C; c++) lp[(size_t)a * C + c] = P.newlp[c];
+    adj[a].erase(b); adj[b].erase(a);
+    for (const PlanItem& it : P.items) {
+      adj[it.c3].erase(b);
+      if (it.fold) {
+        S[it.tr] = it.newS;
+        if (prio[it.t] >= 0.0f) q.erase(Key{prio[it.t], it.t});
+        prio[it.t] = -1.0f; r2[it.t] = -1;
+      } else {
+        r1[it.t] = std::min(a, it.c3); r2[it.t] = std::max(a, it.c3);
+        adj[a][it.c3] = it.t; adj[it.c3][a] = it.t;
+      }
+      store(it.tr, it.newprio);
+    }
+    std::unordered_map<int, int>().swap(adj[b]);
+    parent[b] = a;
+  }
+  void run_executor() {
+    std::vector<long long> wmark(N, 0), rmark(N, 0);
+    std::vector<Key> win;
+    std::vector<Plan> plans;
+    long long round = 0;
+    while (!q.empty()) {
+      round++;
+      win.clear();
+      { auto it = q.begin(); for (int i = 0; i < executor_k && it != q.end(); ++i, ++it) win.push_back(*it); }
+      plans.resize(win.size());
+      for (size_t i = 0; i < win.size(); i++) make_plan(win[i], plans[i]);       // all from the round's start state
+      bool has_best = false; Key best{0.0f, 0};
+      for (size_t i = 0; i < win.size(); i++) {
+        const Plan& P = plans[i];
+        if (i > 0) {
+          if (has_best && best < win[i]) break;                      // a committed pop produced an entry that comes first
+          bool clash = false;
+          if (P.merging) {
+            clash = wmark[P.a] == round || rmark[P.a] == round || wmark[P.b] == round || rmark[P.b] == round;
+            for (const PlanItem& it : P.items) if (wmark[it.c3] == round) { clash = true; break; }
+          } else {
+            clash = wmark[P.a] == round || wmark[P.b] == round;
+          }
+          if (clash) break;
+        }
+        if (P.merging) {
+          wmark[P.a] = rmark[P.a] = wmark[P.b] = rmark[P.b] = round;
+          for (const PlanItem& it : P.items) rmark[it.c3] = round;
+        } else {
+          rmark[P.a] = round; rmark[P.b] = round;
+        }
+        if (P.has_best && (!has_best || P.best < best)) { best = P.best; has_best = true; }
+        apply_plan(P);
+      }
+    }
+    ex_rounds = round;
+  }
+
   void run(const float* cls_p, const float* same_p, const int* offs) {
     N = W * H;
     lp.resize((size_t)N * C); ocls.resize(N); osize.assign(N, 1); parent.resize(N); adj.resize(N);
@@ -251,6 +395,7 @@ struct Model {
         if (f >= 0.0f) q.insert(Key{f, r});
       }
     }
+    if (executor_k) { run_executor(); return; }
     long long ev = 0;
     n_start = live_records;
     float run_min = 3.0e38f;
@@ -400,6 +545,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_REKEY")) m.rekey_study = atoi(e);
   if (const char* e = getenv("XM_RW")) m.rw = atoi(e);
   if (const char* e = getenv("XM_ROUNDS")) m.rounds_k = atoi(e);
+  if (const char* e = getenv("XM_EXECUTOR")) m.executor_k = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   m.finish_study();
@@ -409,6 +555,9 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     fprintf(stderr, "\n");
     if (m.parallel_study >= 2) { m.window_study(16); m.window_study(64); m.window_study(256); }
   }
+  if (m.executor_k)
+    fprintf(stderr, "prefix executor run, window %d: %lld pops, %lld merges in %lld rounds = %.2f pops per round\n", m.executor_k,
+            m.steps, m.merges, m.ex_rounds, (double)m.steps / (double)(m.ex_rounds ? m.ex_rounds : 1));
   if (m.rounds_k) {
     if (m.rs_in_round > 0) m.rs_rounds++;
     fprintf(stderr, "prefix executor, window %d: %lld pops in %lld rounds = %.2f per round; a round ended because the next pop was not the next entry of the window %lld, the window was used up %lld, footprints clashed %lld; rounds by log2 of their length:",
