@@ -65,3 +65,20 @@ def test_prefix_executor_reproduces_the_sequential_order(name, window, monkeypat
     p1, c1, s1 = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias, track=False)
     assert np.array_equal(p0, p1) and np.array_equal(c0, c1)
     assert (s0["steps"], s0["merges"]) == (s1["steps"], s1["merges"])
+
+
+@pytest.mark.parametrize("name", ["cseg_adv_48x48_o0", "cseg_synth_32x64_n60", "cseg_blur_64x128_r2"])
+def test_sorted_front_hands_out_the_queues_best_entries(name, monkeypatch):
+    """The queue the executor would use on the GPU (XM_FRONT=M): a sorted front of the M best entries with the invariant
+    "every entry outside is behind the front's last", rebuilt when fewer than K are left.  Every round's window must
+    be the K best entries of the whole queue (checked inside the model), and the result the sequential one."""
+    g = gu.load(name)
+    sdb, omf, bias = g["spec"]["opts"]
+    monkeypatch.delenv("XM_EXECUTOR", raising=False)
+    monkeypatch.delenv("XM_FRONT", raising=False)
+    p0, c0, s0 = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias, track=False)
+    monkeypatch.setenv("XM_EXECUTOR", "16")
+    monkeypatch.setenv("XM_FRONT", "48")
+    p1, c1, s1 = exact_model.run(g["class_probs"], g["sameness_probs"], g["offsets"], omf, bias, track=False)
+    assert s1["front_errors"] == 0 and s1["front_rebuilds"] > 0
+    assert np.array_equal(p0, p1) and (s0["steps"], s0["merges"]) == (s1["steps"], s1["merges"])

@@ -163,10 +163,34 @@ struct Model {
     return (s * omf + cdl) / den + bias;
   }
 
+  // ---- the sorted FRONT of the executor's queue (XM_FRONT=M with XM_EXECUTOR=K): the M best entries, with the
+  // invariant "every entry outside is behind the front's last"; a store that beats the last goes in (the last
+  // falls out when the front is full), a store of a record that is in the front takes it out, and the front is
+  // rebuilt when fewer than K entries are left.  The model checks every round that the front's first K entries are
+  // the queue's (fr_checks / fr_rebuilds / fr_inserts are reported). ----
+  int front_m = 0;
+  std::vector<Key> front;
+  long long fr_rebuilds = 0, fr_inserts = 0, fr_checks = 0, fr_errors = 0;
+  void front_remove(const Key& k) {
+    auto it = std::lower_bound(front.begin(), front.end(), k);
+    if (it != front.end() && it->r == k.r && it->p == k.p) front.erase(it);
+  }
+  void front_offer(const Key& k) {
+    if (front.empty() || !(k < front.back())) return;            // behind the last: stays outside
+    front.insert(std::lower_bound(front.begin(), front.end(), k), k);
+    fr_inserts++;
+    if ((int)front.size() > front_m) front.pop_back();
+  }
+  void front_rebuild() {
+    front.clear();
+    auto it = q.begin();
+    for (int i = 0; i < front_m && it != q.end(); ++i, ++it) front.push_back(*it);
+    fr_rebuilds++;
+  }
   void store(int r, float f) {
-    if (prio[r] >= 0.0f) q.erase(Key{prio[r], r});
+    if (prio[r] >= 0.0f) { q.erase(Key{prio[r], r}); if (front_m) front_remove(Key{prio[r], r}); }
     prio[r] = f;
-    if (f >= 0.0f) q.insert(Key{f, r});
+    if (f >= 0.0f) { q.insert(Key{f, r}); if (front_m) front_offer(Key{f, r}); }
   }
 
   // touch of object o by event `ev` (popped priority pw): conflict iff the last toucher lies in the subtree
@@ -300,7 +324,8 @@ struct Model {
     if (!P.merging) { store(P.r, P.f); return; }
     merges++;
     const int a = P.a, b = P.b, r = P.r;
-    q.erase(P.key); prio[r] = -1.0f; r2[r] = -1;
+    q.erase(P.key); if (front_m) front_remove(P.key);
+    prio[r] = -1.0f; r2[r] = -1;
     ocls[a] = P.mc; osize[a] = P.newsize;
     for (int c = 0; c < C; c++) lp[(size_t)a * C + c] = P.newlp[c];
     adj[a].erase(b); adj[b].erase(a);
@@ -308,7 +333,7 @@ struct Model {
       adj[it.c3].erase(b);
       if (it.fold) {
         S[it.tr] = it.newS;
-        if (prio[it.t] >= 0.0f) q.erase(Key{prio[it.t], it.t});
+        if (prio[it.t] >= 0.0f) { q.erase(Key{prio[it.t], it.t}); if (front_m) front_remove(Key{prio[it.t], it.t}); }
         prio[it.t] = -1.0f; r2[it.t] = -1;
       } else {
         r1[it.t] = std::min(a, it.c3); r2[it.t] = std::max(a, it.c3);
@@ -327,7 +352,18 @@ struct Model {
     while (!q.empty()) {
       round++;
       win.clear();
-      { auto it = q.begin(); for (int i = 0; i < executor_k && it != q.end(); ++i, ++it) win.push_back(*it); }
+      if (front_m) {
+        if ((int)front.size() < executor_k && front.size() < q.size()) front_rebuild();
+        for (int i = 0; i < executor_k && i < (int)front.size(); i++) win.push_back(front[i]);
+        // (the check: the front's first entries are the queue's)
+        auto it = q.begin();
+        fr_checks++;
+        for (size_t i = 0; i < win.size(); ++i, ++it)
+          if (it == q.end() || it->r != win[i].r || it->p != win[i].p) { fr_errors++; break; }
+        if (win.size() < (size_t)executor_k && win.size() != q.size()) fr_errors++;
+      } else {
+        auto it = q.begin(); for (int i = 0; i < executor_k && it != q.end(); ++i, ++it) win.push_back(*it);
+      }
       plans.resize(win.size());
       for (size_t i = 0; i < win.size(); i++) make_plan(win[i], plans[i]);       // all from the round's start state
       bool has_best = false; Key best{0.0f, 0};
@@ -546,6 +582,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (const char* e = getenv("XM_RW")) m.rw = atoi(e);
   if (const char* e = getenv("XM_ROUNDS")) m.rounds_k = atoi(e);
   if (const char* e = getenv("XM_EXECUTOR")) m.executor_k = atoi(e);
+  if (const char* e = getenv("XM_FRONT")) m.front_m = atoi(e);
   m.C = C; m.O = O; m.W = W; m.H = H; m.omf = omf; m.bias = bias; m.track = track;
   m.run(class_pred, adj_pred, offs);
   m.finish_study();
@@ -558,6 +595,9 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
   if (m.executor_k)
     fprintf(stderr, "prefix executor run, window %d: %lld pops, %lld merges in %lld rounds = %.2f pops per round\n", m.executor_k,
             m.steps, m.merges, m.ex_rounds, (double)m.steps / (double)(m.ex_rounds ? m.ex_rounds : 1));
+  if (m.executor_k && m.front_m)
+    fprintf(stderr, "sorted front of %d entries: %lld rebuilds (one per %.0f pops), %lld inserts, %lld window checks, %lld WRONG windows\n",
+            m.front_m, m.fr_rebuilds, (double)m.steps / (double)(m.fr_rebuilds ? m.fr_rebuilds : 1), m.fr_inserts, m.fr_checks, m.fr_errors);
   if (m.rounds_k) {
     if (m.rs_in_round > 0) m.rs_rounds++;
     fprintf(stderr, "prefix executor, window %d: %lld pops in %lld rounds = %.2f per round; a round ended because the next pop was not the next entry of the window %lld, the window was used up %lld, footprints clashed %lld; rounds by log2 of their length:",
@@ -576,6 +616,7 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     stats[0] = (double)m.steps; stats[1] = (double)m.merges; stats[2] = (double)m.tied_steps;
     stats[3] = (double)m.tied_merges; stats[4] = (double)m.tied_conflicts; stats[5] = (double)m.max_depth;
     stats[6] = (double)m.bump; stats[7] = (double)m.reallocs; stats[8] = (double)m.repop_merges;
+    stats[9] = (double)m.fr_errors; stats[10] = (double)m.fr_rebuilds; stats[11] = (double)m.ex_rounds;
   }
   return 0;
 }

@@ -38,5 +38,6 @@ def run(class_probs, sameness_probs, offsets, omf, bias, clip=True, track=True):
     lib.exact_model_run(cp.ctypes.data_as(fp), sp.ctypes.data_as(fp), C, O, W, H, offs.ctypes.data_as(ip),
                         ctypes.c_float(omf), ctypes.c_float(bias), int(track), part.ctypes.data_as(ip),
                         ocls.ctypes.data_as(ip), stats.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
-    names = ("steps", "merges", "tied_steps", "tied_merges", "tied_conflicts", "max_depth", "arena_entries", "reallocs", "repop_merges")
+    names = ("steps", "merges", "tied_steps", "tied_merges", "tied_conflicts", "max_depth", "arena_entries", "reallocs", "repop_merges",
+             "front_errors", "front_rebuilds", "executor_rounds")
     return part, ocls, {k: int(v) for k, v in zip(names, stats)}
