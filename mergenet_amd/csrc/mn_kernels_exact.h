@@ -73,7 +73,7 @@ struct XCtl {
   long long tied_merges;      // ... of which merged
   long long slot_errors;      // MN_X_CHECK_SLOTS (tests): records / table slots that do not point at each other
   // tie-conflict tracking (see "ties" below): state kept across launches of the loop
-  long long tied_conflicts;   // > 0: a choice among bit-equal priorities touched what another such choice touched
+  long long tied_conflicts;   // > 0: a choice among bit-equal priorities wrote an object that another such choice read or wrote
   int tdepth, tpairs, ttied;  // nesting stack: entries, adjacent entries with equal words, entries popped while tied
   int ttrack;                 // 1: tracking (stops at the first conflict: the verdict is a yes / no)
 };
