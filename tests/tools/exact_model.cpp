@@ -211,6 +211,7 @@ struct Model {
   // The read stamp is not overwritten while it is dangerous (a later read from the toucher's own subtree must not
   // hide it from a write that follows).
   int rw = 1;
+  long long walk_hist[16] = {0}, walk_max = 0;        // records of the absorbed object at a merge, log2 buckets (XM_WALKS=1)
   long long kind_count[4] = {0, 0, 0, 0};              // conflicts: write after write, read after write, write after read, rival
   std::vector<long long> rstamp;
   void touch(int o, long long ev, bool write = true) {
@@ -495,6 +496,7 @@ struct Model {
         }
       }
       int adopted_n = 0;
+      { int bkt = 0; while ((1u << (bkt + 1)) <= adj[b].size() && bkt < 15) bkt++; walk_hist[bkt]++; if ((long long)adj[b].size() > walk_max) walk_max = (long long)adj[b].size(); }
       for (auto& kv : adj[b]) {
         const int c3 = kv.first, t = kv.second;
         touch(c3, ev, false);
@@ -603,6 +605,11 @@ extern "C" int exact_model_run(const float* class_pred, const float* adj_pred, i
     fprintf(stderr, "prefix executor, window %d: %lld pops in %lld rounds = %.2f per round; a round ended because the next pop was not the next entry of the window %lld, the window was used up %lld, footprints clashed %lld; rounds by log2 of their length:",
             m.rounds_k, m.steps, m.rs_rounds, (double)m.steps / (double)(m.rs_rounds ? m.rs_rounds : 1), m.rs_cut_order, m.rs_cut_window, m.rs_cut_clash);
     for (int i = 0; i < 12; i++) fprintf(stderr, " %lld", m.rs_hist[i]);
+    fprintf(stderr, "\n");
+  }
+  if (getenv("XM_WALKS")) {
+    fprintf(stderr, "records of the absorbed object at a merge (longest %lld), by log2 bucket:", m.walk_max);
+    for (int i = 0; i < 16; i++) fprintf(stderr, " %lld", m.walk_hist[i]);
     fprintf(stderr, "\n");
   }
   if (getenv("XM_KINDS"))
